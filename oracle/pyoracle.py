@@ -1,0 +1,200 @@
+"""ctypes loader for the CPU restatement (oracle/sift_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package (siftmetal_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libsift_oracle.so")
+
+FMT_BGRA8, FMT_GRAY8, FMT_GRAYF32 = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("n_octaves", C.c_int32),
+                ("nspo", C.c_int32), ("full_neighbourhood", C.c_int32), ("use_fma", C.c_int32)]
+
+
+extremum_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("scale", "<i4")])
+keypoint_dtype = np.dtype([("octave", "<i4"), ("scale", "<i4"), ("subScale", "<f4"),
+                           ("x", "<i4"), ("y", "<i4"), ("absX", "<f4"), ("absY", "<f4"),
+                           ("normX", "<f4"), ("normY", "<f4"), ("sigma", "<f4"), ("value", "<f4")])
+orientation_dtype = np.dtype([("keypoint", "<i4"), ("count", "<i4"), ("orientations", "<f4", (36,))])
+descriptor_dtype = np.dtype([("valid", "<i4"), ("keypoint", "<i4"), ("theta", "<f4"),
+                             ("features", "<i4", (128,))])
+assert keypoint_dtype.itemsize == 44 and orientation_dtype.itemsize == 152 and descriptor_dtype.itemsize == 524
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "sift_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.so_create.restype = C.c_void_p
+        L.so_create.argtypes = [C.POINTER(Config)]
+        L.so_destroy.argtypes = [C.c_void_p]
+        for f in ("so_octave_width", "so_octave_height"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+        L.so_octave_delta.restype = C.c_float
+        L.so_octave_delta.argtypes = [C.c_void_p, C.c_int]
+        L.so_octave_sigma.restype = C.c_float
+        L.so_octave_sigma.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.so_blur_taps.restype = C.c_int
+        L.so_blur_taps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.so_build_pyramid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        for f in ("so_gaussian", "so_dog"):
+            getattr(L, f).restype = C.POINTER(C.c_float)
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.so_seed.restype = C.POINTER(C.c_float)
+        L.so_seed.argtypes = [C.c_void_p]
+        L.so_extrema.restype = C.c_int
+        L.so_extrema.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.so_refine.restype = C.c_int
+        L.so_refine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.so_orientations.restype = C.c_int
+        L.so_orientations.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.so_descriptors.restype = C.c_int
+        L.so_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int]
+        L.so_detect_describe.restype = C.c_int
+        L.so_detect_describe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.so_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _fmt_of(img):
+    if img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 4:
+        return FMT_BGRA8
+    if img.dtype == np.uint8 and img.ndim == 2:
+        return FMT_GRAY8
+    if img.dtype == np.float32 and img.ndim == 2:
+        return FMT_GRAYF32
+    raise ValueError("image must be HxWx4 u8 (BGRA), HxW u8 or HxW f32")
+
+
+class Oracle:
+    """Per-stage access to the restatement (mirrors the reference's stage boundaries)."""
+
+    def __init__(self, width, height, n_octaves=7, nspo=3, full_neighbourhood=False, use_fma=True):
+        self.cfg = Config(width, height, n_octaves, nspo, int(full_neighbourhood), int(use_fma))
+        self.L = lib()
+        self.h = self.L.so_create(C.byref(self.cfg))
+        if not self.h:
+            raise ValueError("so_create failed")
+        self.n_octaves, self.nspo = n_octaves, nspo
+
+    def close(self):
+        if self.h:
+            self.L.so_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def octave_size(self, o):
+        return self.L.so_octave_width(self.h, o), self.L.so_octave_height(self.h, o)
+
+    def delta(self, o):
+        return self.L.so_octave_delta(self.h, o)
+
+    def sigma(self, o, s):
+        return self.L.so_octave_sigma(self.h, o, s)
+
+    def weights(self, layer):
+        buf = np.zeros(32, np.float32)
+        n = self.L.so_blur_taps(self.h, layer, _ptr(buf))
+        return buf[:n].copy()
+
+    def build_pyramid(self, img):
+        img = np.ascontiguousarray(img)
+        assert img.shape[0] == self.cfg.height and img.shape[1] == self.cfg.width
+        self.L.so_build_pyramid(self.h, _ptr(img), _fmt_of(img), img.strides[0])
+
+    def _view(self, p, o):
+        w, h = self.octave_size(o)
+        return np.ctypeslib.as_array(p, shape=(h, w))
+
+    def gaussian(self, o, s):
+        return self._view(self.L.so_gaussian(self.h, o, s), o)
+
+    def dog(self, o, s):
+        return self._view(self.L.so_dog(self.h, o, s), o)
+
+    def seed(self):
+        return self._view(self.L.so_seed(self.h), 0)
+
+    def extrema(self, o):
+        n = self.L.so_extrema(self.h, o, None, 0)
+        out = np.zeros(n, extremum_dtype)
+        self.L.so_extrema(self.h, o, _ptr(out), n)
+        return out
+
+    def refine(self, o, ext):
+        ext = np.ascontiguousarray(ext)
+        out = np.zeros(len(ext), keypoint_dtype)
+        n = self.L.so_refine(self.h, o, _ptr(ext), len(ext), _ptr(out), len(out))
+        return out[:n].copy()
+
+    def orientations(self, o, kp):
+        kp = np.ascontiguousarray(kp)
+        out = np.zeros(len(kp), orientation_dtype)
+        n = self.L.so_orientations(self.h, o, _ptr(kp), len(kp), _ptr(out), len(out))
+        return out[:n].copy()
+
+    def descriptors(self, o, kp, ori, want_float=False):
+        kp = np.ascontiguousarray(kp)
+        ori = np.ascontiguousarray(ori)
+        nd = int(ori["count"].sum()) if len(ori) else 0
+        out = np.zeros(nd, descriptor_dtype)
+        f32 = np.zeros((nd, 128), np.float32) if want_float else None
+        n = self.L.so_descriptors(self.h, o, _ptr(kp), _ptr(ori), len(ori), _ptr(out), _ptr(f32), nd)
+        assert n == nd
+        return (out, f32) if want_float else out
+
+    def detect_describe_counts(self, img):
+        img = np.ascontiguousarray(img)
+        c = [np.zeros(self.n_octaves, np.int32) for _ in range(4)]
+        total = self.L.so_detect_describe(self.h, _ptr(img), _fmt_of(img), img.strides[0], *[_ptr(a) for a in c])
+        return total, c
+
+    def run(self, img, want_float=False):
+        """Full path; returns per-octave dicts of extrema / keypoints / orientations / descriptors."""
+        self.build_pyramid(img)
+        res = []
+        for o in range(self.n_octaves):
+            ext = self.extrema(o)
+            kp = self.refine(o, ext)
+            ori = self.orientations(o, kp)
+            d = self.descriptors(o, kp, ori, want_float)
+            res.append({"extrema": ext, "keypoints": kp, "orientations": ori,
+                        "descriptors": d[0] if want_float else d,
+                        "features_f32": d[1] if want_float else None})
+        return res
+
+
+def num_threads():
+    return lib().so_num_threads()

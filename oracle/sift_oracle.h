@@ -1,0 +1,110 @@
+/*
+ * sift_oracle.h -- CPU restatement of the lukevanin/SIFTMetal detect+describe path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call it, and
+ * there only as the checker / the timed CPU baseline, never as the thing shipped.
+ *
+ * Parity pin (see DESIGN.md "Oracle"): the reference is Swift + Metal Shading Language and
+ * cannot be built in this image (no swiftc, no Metal; building the .metal files would need a
+ * hand-written stand-in for <metal_stdlib>, which the build rules forbid), so there is no
+ * oracle/_ref.  The restatement is pinned against the golden data the reference's own tests
+ * hold (Tests/SIFTMetalTests/Resources: IPOL sift_anatomy outputs on butterfly.png):
+ *   - Gaussian stack      vs scalespace_butterfly_o*_s*.png          (<= 1.5/255, tight)
+ *   - raw 3-D extrema     vs extra_NES_butterfly.txt (3068 rows)     (exact count with the
+ *                            full 26-neighbour switch; the reference's own 25-neighbour
+ *                            test is a superset)
+ *   - refined keypoints   vs extra_OnEdgeResp_butterfly.txt (1304)   (>=98% within 0.01 px)
+ *   - orientation/descr.  vs butterfly-descriptors.txt               (LOOSE: the reference
+ *                            uses an OpenSIFT-style descriptor, not IPOL's; theta is a
+ *                            known -1/2 bin off) -- descriptor/orientation parity is
+ *                            therefore pinned only statistically; see DESIGN.md.
+ *
+ * Every function cites the reference file:line it follows
+ * (paths relative to the reference repo root).
+ */
+#ifndef SIFT_ORACLE_H
+#define SIFT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO_MAX_WEIGHTS 32          /* Sources/MetalShaders/include/ConvolutionSeries.h:13 */
+#define SO_ORI_BINS 36             /* Sources/MetalShaders/include/SIFTOrientation.h:12  */
+#define SO_DESC_FEATURES 128       /* Sources/MetalShaders/include/SIFTDescriptor.h:14-16 */
+
+enum { SO_FMT_BGRA8 = 0, SO_FMT_GRAY8 = 1, SO_FMT_GRAYF32 = 2 };
+
+typedef struct so_config {
+    int32_t width, height;       /* input image size (SIFT.Configuration.inputSize)          */
+    int32_t n_octaves;           /* reference hard-wires 7 (DifferenceOfGaussians.swift:41)   */
+    int32_t nspo;                /* scales per octave, reference 3 (:46)                      */
+    int32_t full_neighbourhood;  /* 0 = reference's 25-neighbour test, 1 = all 26 (IPOL)      */
+    int32_t use_fma;             /* 1 = blur taps accumulate with fmaf (default), 0 = mul+add */
+} so_config;
+
+/* Record layouts = the reference's shared C structs (Sources/MetalShaders/include/ headers). */
+typedef struct { int32_t x, y, scale; } so_extremum;                 /* SIFTExtrema.h:14-18 */
+
+typedef struct {                                                      /* SIFTKeypoint.swift:11-57 */
+    int32_t octave, scale;
+    float   subScale;
+    int32_t x, y;                 /* scaledCoordinate   */
+    float   absX, absY;           /* absoluteCoordinate */
+    float   normX, normY;         /* normalizedCoordinate */
+    float   sigma, value;
+} so_keypoint;                    /* 44 bytes */
+
+typedef struct {                                                      /* SIFTOrientation.h:30-34 */
+    int32_t keypoint, count;
+    float   orientations[SO_ORI_BINS];
+} so_orientation;                 /* 152 bytes */
+
+typedef struct {                                                      /* SIFTDescriptor.h:37-42 */
+    int32_t valid, keypoint;
+    float   theta;
+    int32_t features[SO_DESC_FEATURES];
+} so_descriptor;                  /* 524 bytes */
+
+typedef struct so_ctx so_ctx;
+
+so_ctx *so_create(const so_config *cfg);
+void    so_destroy(so_ctx *c);
+
+/* schedule queries */
+int   so_octave_width(const so_ctx *c, int o);
+int   so_octave_height(const so_ctx *c, int o);
+float so_octave_delta(const so_ctx *c, int o);
+float so_octave_sigma(const so_ctx *c, int o, int s);
+int   so_blur_taps(const so_ctx *c, int layer /*1..nspo+2, or 0 = seed*/, float *weights_out);
+
+/* dense front end: gray -> 2x bilinear -> seed blur -> per-octave Gaussian stack + DoG */
+void so_build_pyramid(so_ctx *c, const void *pixels, int format, int row_stride_bytes);
+const float *so_gaussian(const so_ctx *c, int o, int s);   /* [h][w]            */
+const float *so_dog(const so_ctx *c, int o, int s);        /* [h][w], s<nspo+2  */
+const float *so_seed(const so_ctx *c);                     /* octave-0 layer 0  */
+
+/* keypoint stages, per octave; return the count (which may exceed cap: nothing past cap is written) */
+int so_extrema(const so_ctx *c, int o, so_extremum *out, int cap);
+int so_refine(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint *out, int cap);
+int so_orientations(const so_ctx *c, int o, const so_keypoint *kp, int n, so_orientation *out, int cap);
+/* expands (keypoint x theta) like SIFTOctave.getDescriptors; features_f32 (optional) receives
+   the 128 pre-quantisation floats per descriptor */
+int so_descriptors(const so_ctx *c, int o, const so_keypoint *kp, const so_orientation *ori, int n_ori,
+                   so_descriptor *out, float *features_f32, int cap);
+
+/* whole path in one call (used by the cpu_baseline timing leg): returns total descriptors,
+   fills per-octave counts [n_octaves] (any pointer may be NULL) */
+int so_detect_describe(so_ctx *c, const void *pixels, int format, int row_stride_bytes,
+                       int32_t *n_extrema, int32_t *n_keypoints, int32_t *n_oriented,
+                       int32_t *n_descriptors);
+
+int so_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
