@@ -1,0 +1,206 @@
+/*
+ * siftmi.h -- C ABI of the MI355X-native SIFT detect+describe path (libsiftmi.so).
+ *
+ * Drop-in boundary for lukevanin/SIFTMetal's hot path.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repo root).  The reference binds its
+ * device code through Swift + the Clang module `MetalShaders` (Sources/MetalShaders/module.modulemap:1-4);
+ * a Swift (or any FFI) host binds this header instead -- see INTEGRATION.md for the Swift stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types
+ *  - every function returns SIFTMI_OK (0) or a negative siftmi_status; siftmi_last_error()
+ *    gives the message.  Nothing aborts (the reference traps via try!/precondition/fatalError).
+ *  - a context is bound to one HIP device, is NOT re-entrant (like the reference's SIFT object:
+ *    one command queue, shared scratch -- SIFT.swift:139), and owns all device memory.
+ *  - pointers returned through `const T **` arguments are owned by the context and stay valid
+ *    until the next call on the same context.
+ *  - there is NO CPU fallback: without a HIP device siftmi_create fails with SIFTMI_E_NODEVICE.
+ */
+#ifndef SIFTMI_H
+#define SIFTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFTMI_VERSION 100
+#define SIFTMI_MAX_OCTAVES 16
+#define SIFTMI_ORIENTATION_BINS 36      /* Sources/MetalShaders/include/SIFTOrientation.h:12   */
+#define SIFTMI_DESCRIPTOR_FEATURES 128  /* Sources/MetalShaders/include/SIFTDescriptor.h:14-16 */
+
+typedef enum siftmi_status {
+    SIFTMI_OK          =  0,
+    SIFTMI_E_BADARG    = -1,
+    SIFTMI_E_CAPACITY  = -2,   /* a per-octave list overflowed its capacity; results are truncated,
+                                  siftmi_last_error() names the list and the size it needed       */
+    SIFTMI_E_HIP       = -3,
+    SIFTMI_E_NODEVICE  = -4,
+    SIFTMI_E_NOMEM     = -5,
+    SIFTMI_E_STATE     = -6    /* e.g. describe before detect */
+} siftmi_status;
+
+/* Pixel formats.  The reference accepts only a .bgra8Unorm texture
+   (Metal Compute/ConvertSRGBToGrayscaleKernel.swift:34); GRAY8/GRAYF32 skip the luma step. */
+typedef enum siftmi_format {
+    SIFTMI_FMT_BGRA8   = 0,
+    SIFTMI_FMT_GRAY8   = 1,
+    SIFTMI_FMT_GRAYF32 = 2
+} siftmi_format;
+
+/* Replaces SIFT.Configuration (SIFT/SIFT.swift:57-103) + DifferenceOfGaussians.Configuration
+   (SIFT/DifferenceOfGaussians.swift:23-51).  Defaults (siftmi_default_config) are the literals
+   the reference actually uses (SIFT/SIFTOctave.swift:217-226, 296-300, 396-401). */
+typedef struct siftmi_config {
+    int32_t width, height;              /* inputSize                                              */
+    int32_t n_octaves;                  /* numberOfOctaves = 7                                    */
+    int32_t nspo;                       /* numberOfScalesPerOctave = 3                            */
+    float   sigma_min;                  /* sigmaMinimum = 0.8                                     */
+    float   delta_min;                  /* deltaMinimum = 0.5 (only 0.5 is supported: 2x seed)    */
+    float   sigma_in;                   /* sigmaInput = 0.5                                       */
+    float   dog_threshold;              /* 0.0133                                                 */
+    float   edge_threshold;             /* 10                                                     */
+    int32_t max_iterations;             /* 5                                                      */
+    float   max_offset;                 /* 0.6                                                    */
+    int32_t image_border;               /* 5                                                      */
+    float   lambda_orientation;         /* 1.5                                                    */
+    float   orientation_threshold;      /* 0.8                                                    */
+    int32_t orientation_smoothing;      /* 6                                                      */
+    int32_t descriptor_scales_per_octave; /* 3: literal at SIFTOctave.swift:398, NOT nspo          */
+    int32_t full_neighbourhood;         /* 0 = reference's 25-neighbour extremum test
+                                           (Metal/SIFTExtrema.metal:84), 1 = all 26               */
+    int32_t max_batch;                  /* frames processed in lock-step per launch (>= 1)        */
+    int32_t max_extrema;                /* per (frame, octave) capacities; 0 = derived from size  */
+    int32_t max_keypoints;
+    int32_t max_descriptors;
+    int32_t keep_descriptor_floats;     /* 1 = also keep the 128 pre-quantisation floats          */
+    int32_t reserved[7];
+} siftmi_config;
+
+/* Replaces SIFTExtremaResult (Sources/MetalShaders/include/SIFTExtrema.h:14-18). */
+typedef struct siftmi_extremum { int32_t x, y, scale; } siftmi_extremum;
+
+/* Replaces SIFTKeypoint (SIFT/SIFTKeypoint.swift:11-57), flattened to 11 x 4 bytes. */
+typedef struct siftmi_keypoint {
+    int32_t octave;
+    int32_t scale;
+    float   sub_scale;
+    int32_t x, y;                       /* scaledCoordinate     */
+    float   abs_x, abs_y;               /* absoluteCoordinate   */
+    float   norm_x, norm_y;             /* normalizedCoordinate */
+    float   sigma;
+    float   value;
+} siftmi_keypoint;                      /* 44 bytes */
+
+/* Replaces SIFTOrientationResult (Sources/MetalShaders/include/SIFTOrientation.h:30-34). */
+typedef struct siftmi_orientation {
+    int32_t keypoint;                   /* index into the octave's keypoint list                   */
+    int32_t count;                      /* -1: rejected by the border filter (SIFTOctave.swift:311-329) */
+    float   orientations[SIFTMI_ORIENTATION_BINS];
+} siftmi_orientation;                   /* 152 bytes */
+
+/* Replaces SIFTDescriptorResult (Sources/MetalShaders/include/SIFTDescriptor.h:37-42) /
+   SIFTDescriptor (SIFT/SIFTDescriptor.swift:12-34).  Features are the reference's 0..255 integers
+   stored as bytes; siftmi_descriptor_to_reference() widens to the 524-byte Int32 record. */
+typedef struct siftmi_descriptor {
+    int32_t keypoint;                   /* index into the octave's keypoint list                   */
+    float   theta;
+    uint8_t features[SIFTMI_DESCRIPTOR_FEATURES];
+} siftmi_descriptor;                    /* 136 bytes */
+
+typedef struct siftmi_descriptor_reference {   /* byte-for-byte SIFTDescriptorResult */
+    int32_t valid;
+    int32_t keypoint;
+    float   theta;
+    int32_t features[SIFTMI_DESCRIPTOR_FEATURES];
+} siftmi_descriptor_reference;          /* 524 bytes */
+
+/* Counters of the last call (replaces the os.Logger counts, SIFT.swift:186). [frame][octave] */
+typedef struct siftmi_stats {
+    int32_t n_frames, n_octaves;
+    const int32_t *raw_extrema;         /* all strict 3-D extrema                                  */
+    const int32_t *candidates;          /* extrema passing the 0.8*threshold / border pre-filter   */
+    const int32_t *keypoints;
+    const int32_t *oriented;            /* keypoints passing the orientation border filter         */
+    const int32_t *descriptors;
+} siftmi_stats;
+
+typedef struct siftmi_ctx siftmi_ctx;
+
+/* --- lifecycle: replaces SIFT.init(device:configuration:) (SIFT/SIFT.swift:112-143) ---------- */
+int  siftmi_default_config(siftmi_config *cfg, int32_t width, int32_t height);
+int  siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ctx **out);
+void siftmi_destroy(siftmi_ctx *ctx);
+const char *siftmi_last_error(void);
+int  siftmi_device_count(void);
+
+/* --- SIFT.getKeypoints(_:) (SIFT/SIFT.swift:147-152) ------------------------------------------
+   pixels: host pointer (on_device = 0) or device pointer (on_device = 1), `format`, rows
+   `row_stride` bytes apart.  Keypoints come back grouped by octave (counts[o], o < n_octaves),
+   each group sorted by (scale, y, x) -- the reference's order is arbitrary (atomics).
+   The pyramid stays resident in the context for a following siftmi_describe. */
+int siftmi_detect(siftmi_ctx *ctx, const void *pixels, int format, size_t row_stride, int on_device,
+                  const siftmi_keypoint **keypoints, int32_t *counts);
+
+/* --- SIFT.getDescriptors(keypointOctaves:) (SIFT/SIFT.swift:207-238) ---------------------------
+   keypoints grouped by octave as returned by siftmi_detect (the caller may have filtered them).
+   descriptor.keypoint indexes the octave's group of the INPUT list. */
+int siftmi_describe(siftmi_ctx *ctx, const siftmi_keypoint *keypoints, const int32_t *counts,
+                    const siftmi_descriptor **descriptors, int32_t *desc_counts);
+
+/* --- detect + describe for a batch of frames, no host round trip between the two -------------
+   Frame f starts at pixels + f * frame_stride.  Results are dense, ordered by (frame, octave):
+   kp_counts / desc_counts are [n_frames][n_octaves].  Frames are processed max_batch at a time. */
+int siftmi_detect_describe_batch(siftmi_ctx *ctx, int32_t n_frames, const void *pixels, int format,
+                                 size_t row_stride, size_t frame_stride, int on_device,
+                                 const siftmi_keypoint **keypoints, const int32_t **kp_counts,
+                                 const siftmi_descriptor **descriptors, const int32_t **desc_counts);
+
+/* Same, everything staying in HBM (input and output are device pointers supplied by the caller,
+   e.g. torch tensors that a following RCCL all-gather reads).  d_counts receives
+   [2][n_frames][n_octaves] int32 (keypoints, then descriptors); d_totals receives {n_kp, n_desc}.
+   Asynchronous on `stream` (a hipStream_t, NULL = the context's stream); no host sync. */
+int siftmi_detect_describe_batch_device(siftmi_ctx *ctx, int32_t n_frames, const void *d_pixels, int format,
+                                        size_t row_stride, size_t frame_stride,
+                                        siftmi_keypoint *d_keypoints, int64_t kp_capacity,
+                                        siftmi_descriptor *d_descriptors, int64_t desc_capacity,
+                                        int32_t *d_counts, int32_t *d_totals, void *stream);
+
+/* --- record conversion (SIFTOctave.swift:470-489 host unpack) -------------------------------- */
+void siftmi_descriptor_to_reference(const siftmi_descriptor *in, int64_t n, siftmi_descriptor_reference *out);
+
+/* --- introspection / parity hooks (state of the last detect/describe call) -------------------- */
+int siftmi_get_stats(siftmi_ctx *ctx, siftmi_stats *out);
+int siftmi_octave_size(siftmi_ctx *ctx, int octave, int32_t *w, int32_t *h, float *delta);
+int siftmi_get_sigma(siftmi_ctx *ctx, int octave, int scale, float *sigma);
+int siftmi_get_weights(siftmi_ctx *ctx, int layer /*0 = seed, 1..nspo+2*/, float *weights, int32_t *count);
+/* Gaussian layer G[octave][layer] of `frame` (of the last sub-batch) -> host, dense [h][w] f32 */
+int siftmi_copy_gaussian(siftmi_ctx *ctx, int frame, int octave, int layer, float *dst);
+/* candidate list of (frame, octave), sorted by (scale, y, x) on the host */
+int siftmi_copy_extrema(siftmi_ctx *ctx, int frame, int octave, siftmi_extremum *dst, int32_t cap, int32_t *count);
+int siftmi_copy_orientations(siftmi_ctx *ctx, int frame, int octave, siftmi_orientation *dst, int32_t cap, int32_t *count);
+/* 128 pre-quantisation floats per descriptor (needs keep_descriptor_floats) */
+int siftmi_copy_descriptor_floats(siftmi_ctx *ctx, int frame, int octave, float *dst, int32_t cap, int32_t *count);
+
+/* --- timing (replaces Utilities/Performance.swift measure(name:) signposts) -------------------
+   Stage ids for siftmi_get_timings: accumulated GPU milliseconds and launch counts since the
+   last siftmi_reset_timings, measured with hipEvents on the context's stream when enabled. */
+enum { SIFTMI_T_SEED = 0, SIFTMI_T_BLUR = 1, SIFTMI_T_DOWNSAMPLE = 2, SIFTMI_T_EXTREMA = 3,
+       SIFTMI_T_REFINE = 4, SIFTMI_T_SORT = 5, SIFTMI_T_ORIENT = 6, SIFTMI_T_DESCRIBE = 7,
+       SIFTMI_T_PACK = 8, SIFTMI_T_COUNT = 9 };
+int siftmi_enable_timings(siftmi_ctx *ctx, int enable);
+int siftmi_reset_timings(siftmi_ctx *ctx);
+int siftmi_get_timings(siftmi_ctx *ctx, double *ms /*[SIFTMI_T_COUNT]*/, int64_t *launches /*[SIFTMI_T_COUNT]*/);
+/* algorithmic bytes one blur launch of `octave` moves for ONE frame: 8 B per octave pixel */
+int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *ctx, int octave);
+/* runs the Gaussian-layer blur kernel alone (layer 1..nspo+2 of `octave`, all max_batch frames)
+   `iters` times on the resident pyramid and returns the mean kernel time in ms (hipEvents) */
+int siftmi_time_blur(siftmi_ctx *ctx, int octave, int layer, int iters, double *ms_per_launch);
+int siftmi_synchronize(siftmi_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIFTMI_H */

@@ -1,0 +1,264 @@
+"""siftmetal_amd -- MI355X-native SIFT detect+describe behind SIFTMetal's API shape.
+
+Host-side mirror of the reference's public interface (names, argument meaning, result types):
+    SIFT(device:configuration:)            Sources/SIFTMetal/SIFT/SIFT.swift:112-143
+    SIFT.getKeypoints(_:)                  SIFT.swift:147-152   -> [[SIFTKeypoint]]  (outer = octave)
+    SIFT.getDescriptors(keypointOctaves:)  SIFT.swift:207-238   -> [[SIFTDescriptor]]
+    SIFTKeypoint / SIFTDescriptor          SIFT/SIFTKeypoint.swift:11-57, SIFT/SIFTDescriptor.swift:12-40
+    IntegralSize                           Utilities/Math.swift:11-19
+All compute happens in libsiftmi.so (hand-written HIP for gfx950, C ABI in include/siftmi.h); this
+module only binds it.  There is no CPU fallback: importing works anywhere, creating a SIFT object
+without a HIP device raises.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import (FMT_BGRA8, FMT_GRAY8, FMT_GRAYF32, SiftmiError, descriptor_dtype, extremum_dtype,  # noqa: F401
+                    keypoint_dtype, orientation_dtype)
+
+__all__ = ["SIFT", "SIFTKeypoint", "SIFTDescriptor", "IntegralSize", "SiftmiError", "Engine"]
+
+
+@dataclass(frozen=True)
+class IntegralSize:                      # Utilities/Math.swift:11-19
+    width: int
+    height: int
+
+
+@dataclass
+class SIFTKeypoint:                      # SIFT/SIFTKeypoint.swift:11-57
+    octave: int
+    scale: int
+    subScale: float
+    scaledCoordinate: Tuple[int, int]
+    absoluteCoordinate: Tuple[float, float]
+    normalizedCoordinate: Tuple[float, float]
+    sigma: float
+    value: float
+
+
+@dataclass
+class SIFTDescriptor:                    # SIFT/SIFTDescriptor.swift:12-40
+    keypoint: SIFTKeypoint
+    theta: float
+    features: List[int]                  # 128 integers 0...255 (IntVector)
+    rawFeatures: List[float] = field(default_factory=list)   # features / 255 (FloatVector), :36-40
+
+    def __post_init__(self):
+        if not self.rawFeatures:
+            self.rawFeatures = [np.float32(f) / np.float32(255) for f in self.features]
+
+
+def _fmt_of(img):
+    if img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 4:
+        return FMT_BGRA8
+    if img.dtype == np.uint8 and img.ndim == 2:
+        return FMT_GRAY8
+    if img.dtype == np.float32 and img.ndim == 2:
+        return FMT_GRAYF32
+    raise ValueError("image must be HxWx4 uint8 (BGRA, the reference's .bgra8Unorm), HxW uint8 or HxW float32")
+
+
+class Engine:
+    """Array-level access to one siftmi context (used by tests, bench.py and the stream driver)."""
+
+    def __init__(self, width, height, device=0, **cfg):
+        self.L = _capi.load()
+        self.cfg = _capi.default_config(width, height, **cfg)
+        h = C.c_void_p()
+        _capi.check(self.L.siftmi_create(C.byref(self.cfg), device, C.byref(h)))
+        self.h = h
+        self.width, self.height = width, height
+        self.n_octaves, self.nspo, self.max_batch = self.cfg.n_octaves, self.cfg.nspo, self.cfg.max_batch
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.siftmi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- schedule ----
+    def octave_size(self, o):
+        w, h, d = C.c_int32(), C.c_int32(), C.c_float()
+        _capi.check(self.L.siftmi_octave_size(self.h, o, C.byref(w), C.byref(h), C.byref(d)))
+        return w.value, h.value, d.value
+
+    def sigma(self, o, s):
+        v = C.c_float()
+        _capi.check(self.L.siftmi_get_sigma(self.h, o, s, C.byref(v)))
+        return v.value
+
+    def weights(self, layer):
+        buf = np.zeros(32, np.float32)
+        n = C.c_int32()
+        _capi.check(self.L.siftmi_get_weights(self.h, layer, buf.ctypes.data, C.byref(n)))
+        return buf[:n.value].copy()
+
+    # ---- SIFT.getKeypoints / getDescriptors at array level ----
+    def detect(self, img, allow_capacity=False):
+        img = np.ascontiguousarray(img)
+        assert img.shape[0] == self.height and img.shape[1] == self.width, "image size != configured inputSize"
+        out = C.c_void_p()
+        counts = np.zeros(self.n_octaves, np.int32)
+        _capi.check(self.L.siftmi_detect(self.h, img.ctypes.data, _fmt_of(img), img.strides[0], 0, C.byref(out),
+                                         counts.ctypes.data_as(C.POINTER(C.c_int32))), allow_capacity)
+        n = int(counts.sum())
+        kps = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 44,))[:n * 44].view(keypoint_dtype).copy()
+        return kps, counts
+
+    def describe(self, kps, counts, allow_capacity=False):
+        kps = np.ascontiguousarray(kps, dtype=keypoint_dtype)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        out = C.c_void_p()
+        dc = np.zeros(self.n_octaves, np.int32)
+        _capi.check(self.L.siftmi_describe(self.h, kps.ctypes.data, counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(out),
+                                           dc.ctypes.data_as(C.POINTER(C.c_int32))), allow_capacity)
+        n = int(dc.sum())
+        d = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 136,))[:n * 136].view(descriptor_dtype).copy()
+        return d, dc
+
+    def detect_describe_batch(self, frames, allow_capacity=False):
+        """frames: [n, H, W(,4)] array.  Returns (keypoints, kp_counts[n, n_oct], descriptors, desc_counts[n, n_oct])."""
+        frames = np.ascontiguousarray(frames)
+        n = frames.shape[0]
+        fmt = _fmt_of(frames[0])
+        pk, pkc, pd, pdc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _capi.check(self.L.siftmi_detect_describe_batch(self.h, n, frames.ctypes.data, fmt, frames.strides[1], frames.strides[0], 0,
+                                                        C.byref(pk), C.byref(pkc), C.byref(pd), C.byref(pdc)), allow_capacity)
+        kc = np.ctypeslib.as_array(C.cast(pkc, C.POINTER(C.c_int32)), shape=(n, self.n_octaves)).copy()
+        dc = np.ctypeslib.as_array(C.cast(pdc, C.POINTER(C.c_int32)), shape=(n, self.n_octaves)).copy()
+        nk, nd = int(kc.sum()), int(dc.sum())
+        kps = np.ctypeslib.as_array(C.cast(pk, C.POINTER(C.c_uint8)), shape=(max(nk, 1) * 44,))[:nk * 44].view(keypoint_dtype).copy()
+        ds = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_uint8)), shape=(max(nd, 1) * 136,))[:nd * 136].view(descriptor_dtype).copy()
+        return kps, kc, ds, dc
+
+    def detect_describe_batch_device(self, n_frames, d_pixels, fmt, row_stride, frame_stride, d_kp, kp_cap, d_desc, desc_cap,
+                                     d_counts, d_totals, stream=None):
+        """All pointers are device addresses (ints); asynchronous on `stream`."""
+        _capi.check(self.L.siftmi_detect_describe_batch_device(self.h, n_frames, d_pixels, fmt, row_stride, frame_stride, d_kp, kp_cap,
+                                                               d_desc, desc_cap, d_counts, d_totals, stream))
+
+    # ---- introspection ----
+    def stats(self):
+        s = _capi.Stats()
+        _capi.check(self.L.siftmi_get_stats(self.h, C.byref(s)))
+        shape = (s.n_frames, s.n_octaves)
+        return {k: np.ctypeslib.as_array(getattr(s, k), shape=shape).copy()
+                for k in ("raw_extrema", "candidates", "keypoints", "oriented", "descriptors")}
+
+    def gaussian(self, o, s, frame=0):
+        w, h, _ = self.octave_size(o)
+        out = np.empty((h, w), np.float32)
+        _capi.check(self.L.siftmi_copy_gaussian(self.h, frame, o, s, out.ctypes.data))
+        return out
+
+    def extrema(self, o, frame=0):
+        n = C.c_int32()
+        _capi.check(self.L.siftmi_copy_extrema(self.h, frame, o, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), extremum_dtype)
+        _capi.check(self.L.siftmi_copy_extrema(self.h, frame, o, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def orientations(self, o, frame=0):
+        n = C.c_int32()
+        _capi.check(self.L.siftmi_copy_orientations(self.h, frame, o, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), orientation_dtype)
+        _capi.check(self.L.siftmi_copy_orientations(self.h, frame, o, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def descriptor_floats(self, o, frame=0):
+        n = C.c_int32()
+        _capi.check(self.L.siftmi_copy_descriptor_floats(self.h, frame, o, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 128), np.float32)
+        _capi.check(self.L.siftmi_copy_descriptor_floats(self.h, frame, o, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    # ---- timing ----
+    def enable_timings(self, on=True):
+        _capi.check(self.L.siftmi_enable_timings(self.h, int(on)))
+
+    def reset_timings(self):
+        _capi.check(self.L.siftmi_reset_timings(self.h))
+
+    def timings(self):
+        ms = np.zeros(len(_capi.T_NAMES), np.float64)
+        n = np.zeros(len(_capi.T_NAMES), np.int64)
+        _capi.check(self.L.siftmi_get_timings(self.h, ms.ctypes.data, n.ctypes.data))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_capi.T_NAMES)}
+
+    def blur_algorithmic_bytes(self, o):
+        return int(self.L.siftmi_blur_algorithmic_bytes(self.h, o))
+
+    def time_blur(self, o, layer, iters=20):
+        v = C.c_double()
+        _capi.check(self.L.siftmi_time_blur(self.h, o, layer, iters, C.byref(v)))
+        return v.value
+
+    def synchronize(self):
+        _capi.check(self.L.siftmi_synchronize(self.h))
+
+
+def _kp_obj(r):
+    return SIFTKeypoint(int(r["octave"]), int(r["scale"]), float(r["sub_scale"]), (int(r["x"]), int(r["y"])),
+                        (float(r["abs_x"]), float(r["abs_y"])), (float(r["norm_x"]), float(r["norm_y"])),
+                        float(r["sigma"]), float(r["value"]))
+
+
+def _kp_rec(k):
+    return (k.octave, k.scale, k.subScale, k.scaledCoordinate[0], k.scaledCoordinate[1], k.absoluteCoordinate[0],
+            k.absoluteCoordinate[1], k.normalizedCoordinate[0], k.normalizedCoordinate[1], k.sigma, k.value)
+
+
+class SIFT:
+    """Mirror of `public final class SIFT` (Sources/SIFTMetal/SIFT/SIFT.swift:55)."""
+
+    @dataclass
+    class Configuration:                 # SIFT.swift:57-103 (+ the octave count the reference hard-wires to 7)
+        inputSize: IntegralSize
+        numberOfOctaves: int = 7
+        numberOfScalesPerOctave: int = 3
+
+    def __init__(self, device=0, configuration=None):
+        """device: HIP device ordinal (the reference takes an MTLDevice)."""
+        if configuration is None:
+            raise ValueError("configuration is required (SIFT.Configuration(inputSize: IntegralSize))")
+        self.configuration = configuration
+        self._engine = Engine(configuration.inputSize.width, configuration.inputSize.height, device=device,
+                              n_octaves=configuration.numberOfOctaves, nspo=configuration.numberOfScalesPerOctave)
+
+    def getKeypoints(self, inputTexture) -> List[List[SIFTKeypoint]]:
+        """inputTexture: HxWx4 uint8 BGRA array (the reference requires a .bgra8Unorm MTLTexture of
+        exactly inputSize); HxW uint8 / float32 luma arrays are accepted as an extension."""
+        kps, counts = self._engine.detect(inputTexture)
+        out, pos = [], 0
+        for o in range(self._engine.n_octaves):
+            out.append([_kp_obj(r) for r in kps[pos:pos + counts[o]]])
+            pos += counts[o]
+        return out
+
+    def getDescriptors(self, keypointOctaves: List[List[SIFTKeypoint]]) -> List[List[SIFTDescriptor]]:
+        if len(keypointOctaves) != self._engine.n_octaves:      # precondition, SIFT.swift:208
+            raise ValueError("keypointOctaves.count must equal the number of octaves")
+        counts = np.array([len(kk) for kk in keypointOctaves], np.int32)
+        flat = np.array([_kp_rec(k) for kk in keypointOctaves for k in kk], dtype=keypoint_dtype)
+        ds, dc = self._engine.describe(flat, counts)
+        out, pos = [], 0
+        for o in range(self._engine.n_octaves):
+            out.append([SIFTDescriptor(keypointOctaves[o][int(r["keypoint"])], float(r["theta"]), r["features"].astype(int).tolist())
+                        for r in ds[pos:pos + dc[o]]])
+            pos += dc[o]
+        return out
+
+    # BASELINE.json's north_star names the API detect()/describe(); keep them as aliases.
+    detect = getKeypoints
+    describe = getDescriptors

@@ -1,0 +1,116 @@
+"""ctypes binding of libsiftmi.so (include/siftmi.h).  No fallback: if the library is missing or
+no HIP device is visible, this raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsiftmi.so")
+
+OK, E_BADARG, E_CAPACITY, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5, -6
+FMT_BGRA8, FMT_GRAY8, FMT_GRAYF32 = 0, 1, 2
+T_NAMES = ["seed", "blur", "downsample", "extrema", "refine", "sort", "orient", "describe", "pack"]
+
+EXPORTS = [
+    "siftmi_default_config", "siftmi_create", "siftmi_destroy", "siftmi_last_error", "siftmi_device_count",
+    "siftmi_detect", "siftmi_describe", "siftmi_detect_describe_batch", "siftmi_detect_describe_batch_device",
+    "siftmi_descriptor_to_reference", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
+    "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_extrema", "siftmi_copy_orientations",
+    "siftmi_copy_descriptor_floats", "siftmi_enable_timings", "siftmi_reset_timings", "siftmi_get_timings",
+    "siftmi_blur_algorithmic_bytes", "siftmi_time_blur", "siftmi_synchronize",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("n_octaves", C.c_int32), ("nspo", C.c_int32),
+                ("sigma_min", C.c_float), ("delta_min", C.c_float), ("sigma_in", C.c_float),
+                ("dog_threshold", C.c_float), ("edge_threshold", C.c_float), ("max_iterations", C.c_int32),
+                ("max_offset", C.c_float), ("image_border", C.c_int32), ("lambda_orientation", C.c_float),
+                ("orientation_threshold", C.c_float), ("orientation_smoothing", C.c_int32),
+                ("descriptor_scales_per_octave", C.c_int32), ("full_neighbourhood", C.c_int32),
+                ("max_batch", C.c_int32), ("max_extrema", C.c_int32), ("max_keypoints", C.c_int32),
+                ("max_descriptors", C.c_int32), ("keep_descriptor_floats", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_octaves", C.c_int32)] + \
+               [(n, C.POINTER(C.c_int32)) for n in ("raw_extrema", "candidates", "keypoints", "oriented", "descriptors")]
+
+
+extremum_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("scale", "<i4")])
+keypoint_dtype = np.dtype([("octave", "<i4"), ("scale", "<i4"), ("sub_scale", "<f4"), ("x", "<i4"), ("y", "<i4"),
+                           ("abs_x", "<f4"), ("abs_y", "<f4"), ("norm_x", "<f4"), ("norm_y", "<f4"),
+                           ("sigma", "<f4"), ("value", "<f4")])
+orientation_dtype = np.dtype([("keypoint", "<i4"), ("count", "<i4"), ("orientations", "<f4", (36,))])
+descriptor_dtype = np.dtype([("keypoint", "<i4"), ("theta", "<f4"), ("features", "u1", (128,))])
+descriptor_reference_dtype = np.dtype([("valid", "<i4"), ("keypoint", "<i4"), ("theta", "<f4"), ("features", "<i4", (128,))])
+assert keypoint_dtype.itemsize == 44 and descriptor_dtype.itemsize == 136
+assert orientation_dtype.itemsize == 152 and descriptor_reference_dtype.itemsize == 524
+
+
+class SiftmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("siftmi error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libsiftmi.so (built in-tree by __graft_entry__.build() / make -C siftmetal_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libsiftmi.so not built: run `make -C siftmetal_amd/csrc` (hipcc, gfx950). "
+                          "There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    L.siftmi_default_config.argtypes = [C.POINTER(Config), C.c_int32, C.c_int32]
+    L.siftmi_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(vp)]
+    L.siftmi_destroy.argtypes = [vp]
+    L.siftmi_destroy.restype = None
+    L.siftmi_last_error.restype = C.c_char_p
+    L.siftmi_detect.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), i32p]
+    L.siftmi_describe.argtypes = [vp, vp, i32p, C.POINTER(vp), i32p]
+    L.siftmi_detect_describe_batch.argtypes = [vp, C.c_int32, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
+                                               C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.siftmi_detect_describe_batch_device.argtypes = [vp, C.c_int32, vp, C.c_int, C.c_size_t, C.c_size_t,
+                                                      vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
+    L.siftmi_descriptor_to_reference.argtypes = [vp, C.c_int64, vp]
+    L.siftmi_descriptor_to_reference.restype = None
+    L.siftmi_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.siftmi_octave_size.argtypes = [vp, C.c_int, i32p, i32p, C.POINTER(C.c_float)]
+    L.siftmi_get_sigma.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.siftmi_get_weights.argtypes = [vp, C.c_int, vp, i32p]
+    L.siftmi_copy_gaussian.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+    L.siftmi_copy_extrema.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, i32p]
+    L.siftmi_copy_orientations.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, i32p]
+    L.siftmi_copy_descriptor_floats.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, i32p]
+    L.siftmi_enable_timings.argtypes = [vp, C.c_int]
+    L.siftmi_reset_timings.argtypes = [vp]
+    L.siftmi_get_timings.argtypes = [vp, vp, vp]
+    L.siftmi_blur_algorithmic_bytes.argtypes = [vp, C.c_int]
+    L.siftmi_blur_algorithmic_bytes.restype = C.c_int64
+    L.siftmi_time_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.siftmi_synchronize.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(rc, allow_capacity=False):
+    if rc == OK or (allow_capacity and rc == E_CAPACITY):
+        return rc
+    raise SiftmiError(rc, load().siftmi_last_error().decode("utf-8", "replace"))
+
+
+def default_config(width, height, **overrides):
+    cfg = Config()
+    check(load().siftmi_default_config(C.byref(cfg), width, height))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError("siftmi_config has no field %r" % k)
+        setattr(cfg, k, v)
+    return cfg

@@ -1,0 +1,627 @@
+// keypoint_kernels.hip.h -- DoG extrema, sub-pixel refinement, orientation and descriptor
+// kernels for gfx950 (MI355X).
+//
+// Reference kernels these replace (one thread per item, serial window loops, a blocking
+// command buffer per stage and octave):
+//   siftExtremaList  Sources/MetalShaders/Metal/SIFTExtrema.metal:62-110
+//   siftInterpolate  Sources/MetalShaders/Metal/SIFTInterpolate.metal:193-300
+//   siftGradient     Sources/MetalShaders/Metal/SIFTGradient.metal:15-39
+//   siftOrientation  Sources/MetalShaders/Metal/SIFTOrientation.metal:140-175
+//   siftDescriptors  Sources/MetalShaders/Metal/SIFTDescriptor.metal:120-237
+// and the Swift glue between them (Sources/SIFTMetal/SIFT/SIFTOctave.swift:198-492).
+//
+// MI355X design: nothing but the Gaussian stack lives in HBM.  DoG values are formed on the fly
+// (D[s] = G[s+1] - G[s], the same single f32 subtraction as Subtract.metal:17-19), gradients are
+// evaluated on demand from the Gaussian layer (same ops as siftGradient), all lists are
+// device-resident with device-side counters, every stage is launched once per sub-batch for all
+// (frame, octave) groups with grid-stride loops over the device counts, and the window loops of
+// orientation / descriptor are spread over the 64 lanes of a wavefront with LDS histograms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dense_kernels.hip.h"
+
+namespace siftmi {
+
+#define SIFTMI_PI_F 3.14159265358979323846264338327950288f
+
+constexpr int MAX_OCT = 16;
+constexpr int ORI_BINS = 36;
+constexpr int DESC_N = 128;
+
+struct KeypointRec {            // == siftmi_keypoint (include/siftmi.h), 44 bytes
+    int32_t octave, scale; float sub_scale; int32_t x, y;
+    float abs_x, abs_y, norm_x, norm_y, sigma, value;
+};
+struct ExtremumRec { int32_t x, y, scale; };
+struct DescriptorRec { int32_t keypoint; float theta; uint8_t features[DESC_N]; };   // 136 bytes
+struct DescInput { int32_t keypoint; float theta; };
+
+// Per-context tables handed to every keypoint-stage kernel by value (kernarg -> SGPRs).
+struct PyramidDesc {
+    const float *gauss;                // frame 0, octave 0, layer 0
+    size_t frame_stride;               // floats between frames
+    size_t oct_offset[MAX_OCT];        // floats from the frame base to G[o][0]
+    int32_t w[MAX_OCT], h[MAX_OCT];
+    float delta[MAX_OCT];
+    float sigma0[MAX_OCT], sigma1[MAX_OCT];   // sigmas[0], sigmas[1] of the octave (SIFTOctave.swift:211)
+    float sigmas[MAX_OCT][8];          // sigmas[s], s < nspo+3 <= 8
+    int32_t n_octaves, nspo;
+    int32_t cap_ext[MAX_OCT], cap_kp[MAX_OCT], cap_desc[MAX_OCT];
+    size_t ext_off[MAX_OCT], kp_off[MAX_OCT], desc_off[MAX_OCT];   // element offsets of the octave's segment inside a frame's segment
+    size_t ext_frame, kp_frame, desc_frame;                        // elements per frame
+};
+
+struct DetectParams {              // SIFTInterpolateParameters (SIFTInterpolate.h:14-23) + literals
+    float dog_threshold, edge_threshold, max_offset;
+    int32_t max_iterations, border, full_neighbourhood;
+    float lambda_ori, ori_threshold;
+    int32_t ori_smoothing, desc_scales_per_octave;
+};
+
+__device__ __forceinline__ const float *layer_ptr(const PyramidDesc &p, int frame, int o, int s) {
+    return p.gauss + (size_t)frame * p.frame_stride + p.oct_offset[o] + (size_t)s * p.w[o] * p.h[o];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Extrema: Sources/MetalShaders/Metal/SIFTExtrema.metal:62-110.
+// One lane per column, each workgroup walks EH rows with a 3-row sliding window of DoG values for
+// all nspo+2 layers held in registers.  Strict test against neighbours 1..25 of the reference's
+// 26-entry table (entry 0 = (-1,-1,-1) skipped unless full_neighbourhood).  The soft-threshold /
+// border pre-filter that the reference applies at refinement entry (SIFTInterpolate.metal:208,
+// :223) is applied at emission so that noise extrema never reach the list; raw_count still counts
+// every strict extremum.
+template <int NS>
+__global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParams prm, int o, int EH,
+                                                     ExtremumRec *__restrict__ lists, int32_t *__restrict__ cand_count,
+                                                     int32_t *__restrict__ raw_count) {
+    constexpr int ND = NS + 2;
+    const int w = P.w[o], h = P.h[o];
+    const int frame = blockIdx.z, group = frame * P.n_octaves + o;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int ya = blockIdx.y * EH + 1;                    // first output row of this block
+    const int yb = min(ya + EH, h - 1);                    // one past the last output row
+    if (ya >= yb) return;
+    const size_t n = (size_t)w * h;
+    const float *g0 = layer_ptr(P, frame, o, 0);
+    const bool active = (x >= 1 && x <= w - 2);
+    const int xc = min(max(x, 1), max(w - 2, 1));          // clamped column so edge lanes load safely
+    if (w < 3) return;
+
+    float d[3][ND][3];
+    auto load_row = [&](int y, float (&row)[ND][3]) {
+        float gprev[3], gcur[3];
+        const float *p = g0 + (size_t)y * w + xc;
+        gprev[0] = p[-1]; gprev[1] = p[0]; gprev[2] = p[1];
+#pragma unroll
+        for (int l = 0; l < ND; l++) {
+            const float *q = p + (size_t)(l + 1) * n;
+            gcur[0] = q[-1]; gcur[1] = q[0]; gcur[2] = q[1];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { row[l][c] = gcur[c] - gprev[c]; gprev[c] = gcur[c]; }
+        }
+    };
+    load_row(ya - 1, d[0]);
+    load_row(ya, d[1]);
+    const float pre = prm.dog_threshold * 0.8f;
+    const int border = prm.border;
+    for (int y = ya; y < yb; y++) {
+        load_row(y + 1, d[2]);
+#pragma unroll
+        for (int s = 1; s <= NS; s++) {
+            const float v = d[1][s][1];
+            float mn = +1000.0f, mx = -1000.0f;
+#pragma unroll
+            for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0 && dz == 0) continue;
+                        const float nv = d[1 + dy][s + dz][1 + dx];
+                        if (dx == -1 && dy == -1 && dz == -1) {        // table entry 0
+                            if (prm.full_neighbourhood) { mn = fminf(mn, nv); mx = fmaxf(mx, nv); }
+                        } else {
+                            mn = fminf(mn, nv); mx = fmaxf(mx, nv);
+                        }
+                    }
+            const bool ext = active && ((v < mn) || (v > mx));
+            if (ext) {
+                atomicAdd(&raw_count[group], 1);
+                const bool oob = x < border || x > w - border - 1 || y < border || y > h - border - 1;
+                if (fabsf(v) > pre && !oob) {
+                    const int idx = atomicAdd(&cand_count[group], 1);
+                    if (idx < P.cap_ext[o]) {
+                        ExtremumRec e; e.x = x; e.y = y; e.scale = s;
+                        lists[(size_t)frame * P.ext_frame + P.ext_off[o] + idx] = e;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { d[0][l][c] = d[1][l][c]; d[1][l][c] = d[2][l][c]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Refinement: SIFTInterpolate.metal:17-300 + SIFTOctave.interpolateKeypoints (SIFTOctave.swift:205-288)
+struct DogTex {
+    const float *g; int w, h, nd; size_t n;
+    __device__ __forceinline__ float rd(int x, int y, int s) const {
+        if (x < 0 || y < 0 || s < 0 || x >= w || y >= h || s >= nd) return 0.0f;
+        const float *p = g + (size_t)s * n + (size_t)y * w + x;
+        return p[n] - p[0];
+    }
+};
+
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float r[3]) {
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ __forceinline__ void derivatives3d(const DogTex &t, int x, int y, int s, float dD[3]) {   // :64-87
+    const float pzz = t.rd(x + 1, y, s), nzz = t.rd(x - 1, y, s);
+    const float zpz = t.rd(x, y + 1, s), znz = t.rd(x, y - 1, s);
+    const float zzp = t.rd(x, y, s + 1), zzn = t.rd(x, y, s - 1);
+    dD[0] = (pzz - nzz) * 0.5f; dD[1] = (zpz - znz) * 0.5f; dD[2] = (zzp - zzn) * 0.5f;
+}
+
+__device__ void interpolation_step(const DogTex &t, int x, int y, int s, float alpha[3]) {   // :90-176, Common.hpp:34-47
+    const float zzz = t.rd(x, y, s);
+    const float pzz = t.rd(x + 1, y, s), nzz = t.rd(x - 1, y, s);
+    const float zpz = t.rd(x, y + 1, s), znz = t.rd(x, y - 1, s);
+    const float zzp = t.rd(x, y, s + 1), zzn = t.rd(x, y, s - 1);
+    const float ppz = t.rd(x + 1, y + 1, s), nnz = t.rd(x - 1, y - 1, s);
+    const float npz = t.rd(x - 1, y + 1, s), pnz = t.rd(x + 1, y - 1, s);
+    const float pzp = t.rd(x + 1, y, s + 1), nzp = t.rd(x - 1, y, s + 1);
+    const float zpp = t.rd(x, y + 1, s + 1), znp = t.rd(x, y - 1, s + 1);
+    const float pzn = t.rd(x + 1, y, s - 1), nzn = t.rd(x - 1, y, s - 1);
+    const float zpn = t.rd(x, y + 1, s - 1), znn = t.rd(x, y - 1, s - 1);
+    const float dxx = pzz + nzz - 2.0f * zzz;
+    const float dyy = zpz + znz - 2.0f * zzz;
+    const float dss = zzp + zzn - 2.0f * zzz;
+    const float dxy = (ppz - npz - pnz + nnz) * 0.25f;
+    const float dxs = (pzp - nzp - pzn + nzn) * 0.25f;
+    const float dys = (zpp - znp - zpn + znn) * 0.25f;
+    const float x0[3] = {dxx, dxy, dxs}, x1[3] = {dxy, dyy, dys}, x2[3] = {dxs, dys, dss};
+    float c12[3], c20[3], c01[3];
+    cross3(x1, x2, c12); cross3(x2, x0, c20); cross3(x0, x1, c01);
+    const float det = x0[0] * c12[0] + x0[1] * c12[1] + x0[2] * c12[2];
+    const float inv = 1.0f / det;
+    float dD[3];
+    derivatives3d(t, x, y, s, dD);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float h0 = -1.0f * (inv * c12[k]), h1 = -1.0f * (inv * c20[k]), h2 = -1.0f * (inv * c01[k]);
+        alpha[k] = h0 * dD[0] + h1 * dD[1] + h2 * dD[2];
+    }
+}
+
+__device__ __forceinline__ bool is_on_edge(const DogTex &t, int x, int y, int s, float edgeThreshold) {   // :17-61
+    const float v = t.rd(x, y, s);
+    const float zn = t.rd(x, y - 1, s), zp = t.rd(x, y + 1, s);
+    const float pz = t.rd(x + 1, y, s), nz = t.rd(x - 1, y, s);
+    const float pp = t.rd(x + 1, y + 1, s), np = t.rd(x - 1, y + 1, s);
+    const float pn = t.rd(x + 1, y - 1, s), nn = t.rd(x - 1, y - 1, s);
+    const float hxx = zn + zp - 2.0f * v;
+    const float hyy = pz + nz - 2.0f * v;
+    const float hxy = ((pp - np) - (pn - nn)) * 0.25f;
+    const float trace = hxx + hyy;
+    const float determinant = (hxx * hyy) - (hxy * hxy);
+    if (determinant <= 0.0f) return true;
+    const float threshold = ((edgeThreshold + 1.0f) * (edgeThreshold + 1.0f)) / edgeThreshold;
+    const float curvature = (trace * trace) / determinant;
+    return curvature >= threshold;
+}
+
+__device__ __forceinline__ bool out_of_bounds(int x, int y, int s, int w, int h, int scales, int border) {   // :179-190
+    return x < border || x > w - border - 1 || y < border || y > h - border - 1 || s < 1 || s > scales;
+}
+
+// grid: (blocks, n_groups); group = frame * n_octaves + octave; grid-stride over the candidates.
+// Survivors are appended (unordered) to kp_tmp with a 64-bit sort key; sort_keypoints_kernel
+// orders them.
+__global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams prm,
+                                                    const ExtremumRec *__restrict__ lists, const int32_t *__restrict__ cand_count,
+                                                    KeypointRec *__restrict__ kp_tmp, unsigned long long *__restrict__ kp_keys,
+                                                    int32_t *__restrict__ kp_count) {
+    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(cand_count[group], P.cap_ext[o]);
+    const int w = P.w[o], h = P.h[o];
+    const DogTex t = {layer_ptr(P, frame, o, 0), w, h, P.nspo + 2, (size_t)w * h};
+    const float delta = P.delta[o];
+    const float sigmaRatio = P.sigma1[o] / P.sigma0[o];
+    const ExtremumRec *list = lists + (size_t)frame * P.ext_frame + P.ext_off[o];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        const ExtremumRec e = list[k];
+        int x = e.x, y = e.y, s = e.scale;
+        float value = t.rd(x, y, s);
+        if (fabsf(value) <= prm.dog_threshold * 0.8f) continue;
+        if (out_of_bounds(x, y, s, w, h, P.nspo, prm.border)) continue;
+        bool converged = false, dropped = false;
+        float alpha[3] = {0.0f, 0.0f, 0.0f};
+        int i = 0;
+        while (i < prm.max_iterations) {
+            interpolation_step(t, x, y, s, alpha);
+            if (fabsf(alpha[0]) < prm.max_offset && fabsf(alpha[1]) < prm.max_offset && fabsf(alpha[2]) < prm.max_offset) {
+                converged = true;
+                break;
+            }
+            if (alpha[0] > +prm.max_offset) x += 1;
+            if (alpha[0] < -prm.max_offset) x -= 1;
+            if (alpha[1] > +prm.max_offset) y += 1;
+            if (alpha[1] < -prm.max_offset) y -= 1;
+            if (alpha[2] > +prm.max_offset) s += 1;
+            if (alpha[2] < -prm.max_offset) s -= 1;
+            if (out_of_bounds(x, y, s, w, h, P.nspo, prm.border)) { dropped = true; break; }
+            i += 1;
+        }
+        if (dropped || !converged) continue;
+        {
+            float dD[3];
+            derivatives3d(t, x, y, s, dD);
+            const float cx = dD[0] * alpha[0];                  // :96-99 x term only
+            value = t.rd(x, y, s) + cx * 0.5f;
+        }
+        if (fabsf(value) <= prm.dog_threshold) continue;
+        if (is_on_edge(t, x, y, s, prm.edge_threshold)) continue;
+        const int idx = atomicAdd(&kp_count[group], 1);
+        if (idx >= P.cap_kp[o]) continue;
+        KeypointRec r;                                          // SIFTOctave.swift:266-284
+        r.octave = o; r.scale = s; r.sub_scale = alpha[2];
+        r.x = x; r.y = y;
+        r.abs_x = ((float)x + alpha[0]) * delta;
+        r.abs_y = ((float)y + alpha[1]) * delta;
+        r.norm_x = (float)x / (float)w;
+        r.norm_y = (float)y / (float)h;
+        r.sigma = P.sigmas[o][s] * powf(sigmaRatio, alpha[2]);
+        r.value = value;
+        const size_t slot = (size_t)frame * P.kp_frame + P.kp_off[o] + idx;
+        kp_tmp[slot] = r;
+        const unsigned int kref = (unsigned int)((s * h + y) * w + x);
+        const unsigned int korg = (unsigned int)((e.scale * h + e.y) * w + e.x);
+        kp_keys[slot] = ((unsigned long long)kref << 32) | korg;
+    }
+}
+
+// Rank sort per (frame, octave) group: deterministic order (scale, y, x, then originating
+// extremum) for lists whose append order came from atomics.  O(n^2) compares, n is a few
+// thousand; keys are unique.
+__global__ __launch_bounds__(256) void sort_keypoints_kernel(PyramidDesc P, const KeypointRec *__restrict__ kp_tmp,
+                                                            const unsigned long long *__restrict__ kp_keys,
+                                                            const int32_t *__restrict__ kp_count, KeypointRec *__restrict__ kp_sorted) {
+    __shared__ unsigned long long tile[1024];
+    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(kp_count[group], P.cap_kp[o]);
+    const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        const unsigned long long key = (i < n) ? kp_keys[base + i] : ~0ull;
+        int rank = 0;
+        for (int j0 = 0; j0 < n; j0 += 1024) {
+            __syncthreads();
+            for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = (j0 + j < n) ? kp_keys[base + j0 + j] : ~0ull;
+            __syncthreads();
+            const int m = min(1024, n - j0);
+            for (int j = 0; j < m; j++) rank += (tile[j] < key) ? 1 : 0;
+        }
+        if (i < n) kp_sorted[base + rank] = kp_tmp[base + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient on demand: SIFTGradient.metal:15-39 (atan2(tx, ty) -- argument order as in the
+// reference -- and |grad| of central differences, mirror edges); outside the image -> (0, 0).
+__device__ __forceinline__ void gradient_at(const float *g, int w, int h, int gx, int gy, float &theta, float &mag) {
+    if (gx < 0 || gy < 0 || gx >= w || gy >= h) { theta = 0.0f; mag = 0.0f; return; }
+    const int px = symm(gx + 1, w), mx = symm(gx - 1, w);
+    const int py = symm(gy + 1, h), my = symm(gy - 1, h);
+    auto rd = [&](int x, int y) -> float { return (x < 0 || y < 0 || x >= w || y >= h) ? 0.0f : g[(size_t)y * w + x]; };
+    const float tx = (rd(px, gy) - rd(mx, gy)) * 0.5f;
+    const float ty = (rd(gx, py) - rd(gx, my)) * 0.5f;
+    theta = atan2f(tx, ty);
+    mag = sqrtf(tx * tx + ty * ty);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Orientation: SIFTOctave.getKeypointOrientations (SIFTOctave.swift:290-382) + SIFTOrientation.metal.
+// One wavefront per keypoint; the (2r+1)^2 window is strided over the 64 lanes into a 36-bin LDS
+// histogram (ds_add_f32); smoothing / peak search run on lanes 0..35 with cross-lane shuffles.
+// ori_count[k] = -1 when the host-side border filter of the reference rejects the keypoint.
+__global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectParams prm,
+                                                         const KeypointRec *__restrict__ kps, const int32_t *__restrict__ kp_count,
+                                                         int32_t *__restrict__ ori_count, float *__restrict__ ori_angles) {
+    __shared__ float hist_all[4][ORI_BINS + 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *hist = hist_all[wv];
+    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(kp_count[group], P.cap_kp[o]);
+    const int w = P.w[o], h = P.h[o];
+    const float delta = P.delta[o], lambda = prm.lambda_ori;
+    const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
+    for (int k = blockIdx.x * 4 + wv; k < n; k += gridDim.x * 4) {
+        const KeypointRec kp = kps[base + k];
+        bool reject;
+        {   // SIFTOctave.swift:303-329
+            const float minX = 1.0f, minY = 1.0f, maxX = (float)(w - 2), maxY = (float)(h - 2);
+            const float x = kp.abs_x / delta, y = kp.abs_y / delta;
+            const float sigma = kp.sigma / delta;
+            const float r = ceilf(3.0f * lambda * sigma);
+            reject = (floorf(x - r) < minX) || (ceilf(x + r) > maxX) || (floorf(y - r) < minY) || (ceilf(y + r) > maxY);
+        }
+        if (reject) {
+            if (lane == 0) ori_count[base + k] = -1;
+            continue;
+        }
+        const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // :333-334 Int32 truncation
+        const float *g = layer_ptr(P, frame, o, kp.scale);
+        if (lane < ORI_BINS) hist[lane] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        {   // SIFTOrientation.metal:87-136
+            const int x = (int)roundf((float)absoluteX / delta);
+            const int y = (int)roundf((float)absoluteY / delta);
+            const float sigma = kp.sigma / delta;
+            const float exponentDenominator = 2.0f * lambda * lambda;
+            const int r = (int)ceilf(3.0f * lambda * sigma);
+            const int side = 2 * r + 1, total = side * side;
+            for (int idx = lane; idx < total; idx += 64) {
+                const int jj = idx / side, ii = idx - jj * side;
+                const int j = jj - r, i = ii - r;
+                const float u = (float)i / sigma, v = (float)j / sigma;
+                const float r2 = u * u + v * v;
+                const float wgt = expf(-r2 / exponentDenominator);
+                float orientation, magnitude;
+                gradient_at(g, w, h, x + i, y + j, orientation, magnitude);
+                const float t = orientation / (2.0f * SIFTMI_PI_F);
+                int bin = (int)roundf(t * (float)ORI_BINS);
+                if (bin < 0) bin += ORI_BINS;
+                if (bin >= ORI_BINS) bin -= ORI_BINS;
+                const float m = wgt * magnitude;
+                atomicAdd(&hist[bin], m);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int li = lane < ORI_BINS ? lane : 0;
+        float hv = hist[li];
+        const int lm = (li + ORI_BINS - 1) % ORI_BINS, lp = (li + 1) % ORI_BINS;
+        for (int it = 0; it < prm.ori_smoothing; it++) {               // :67-84
+            const float h0 = __shfl(hv, lm), h2 = __shfl(hv, lp);
+            hv = (h0 + hv + h2) / 3.0f;
+        }
+        float mxv = (lane < ORI_BINS) ? hv : -3.0e38f;                // :44-47 (max is order-free)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, off));
+        const float threshold = prm.ori_threshold * mxv;
+        const float hm = __shfl(hv, lm), hp = __shfl(hv, lp);
+        const bool peak = (lane < ORI_BINS) && (hv > threshold) && (hv > hm) && (hv > hp);
+        const unsigned long long mask = __ballot(peak);
+        if (peak) {                                                    // :16-33, :52-61
+            const float offset = (hm - hp) / (2.0f * (hm + hp - 2.0f * hv));
+            const float tbin = ((float)lane + offset) / (float)ORI_BINS;
+            const float tau = 2.0f * SIFTMI_PI_F;
+            float orientation = tbin * tau;
+            if (orientation < 0.0f) orientation += tau;
+            if (orientation >= tau) orientation -= tau;
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            ori_angles[(base + k) * ORI_BINS + pos] = orientation;
+        }
+        if (lane == 0) ori_count[base + k] = __popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Exclusive scan of the orientation counts of one group -> descriptor inputs in keypoint order
+// (SIFTOctave.swift:411-424 expansion).  One 1024-thread workgroup per group.
+__global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P, const int32_t *__restrict__ kp_count,
+                                                                 const int32_t *__restrict__ ori_count, const float *__restrict__ ori_angles,
+                                                                 DescInput *__restrict__ desc_in, int32_t *__restrict__ desc_count,
+                                                                 int32_t *__restrict__ oriented_count) {
+    __shared__ int part[1024];
+    __shared__ int part2[1024];
+    const int group = blockIdx.x, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(kp_count[group], P.cap_kp[o]);
+    const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
+    const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
+    const int per = (n + 1023) / 1024;
+    const int k0 = threadIdx.x * per, k1 = min(k0 + per, n);
+    int sum = 0, nori = 0;
+    for (int k = k0; k < k1; k++) { const int c = ori_count[kbase + k]; sum += max(c, 0); nori += (c >= 0); }
+    part[threadIdx.x] = sum; part2[threadIdx.x] = nori;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan
+        int a = 0, b = 0;
+        if ((int)threadIdx.x >= off) { a = part[threadIdx.x - off]; b = part2[threadIdx.x - off]; }
+        __syncthreads();
+        part[threadIdx.x] += a; part2[threadIdx.x] += b;
+        __syncthreads();
+    }
+    int pos = part[threadIdx.x] - sum;
+    for (int k = k0; k < k1; k++) {
+        const int c = ori_count[kbase + k];
+        for (int t = 0; t < c; t++, pos++) {
+            if (pos < P.cap_desc[o]) {
+                DescInput d; d.keypoint = k; d.theta = ori_angles[(kbase + k) * ORI_BINS + t];
+                desc_in[dbase + pos] = d;
+            }
+        }
+    }
+    if (threadIdx.x == 1023) { desc_count[group] = part[1023]; oriented_count[group] = part2[1023]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Descriptor: SIFTOctave.getDescriptors (SIFTOctave.swift:384-492) + SIFTDescriptor.metal:15-237.
+// One wavefront per (keypoint, theta); the (2R+1)^2 rotated window is strided over the lanes and
+// scattered trilinearly into a 4x4x8 LDS histogram (ds_add_f32); the two L2 normalisations are
+// wave reductions.  Samples whose truncated coordinate leaves the image contribute nothing (the
+// reference's behaviour there is undefined).
+__device__ __forceinline__ void add_value(float *patch, int x, int y, int b, float value) {   // :59-79
+    if (x < 0 || x >= 4 || y < 0 || y >= 4) return;
+    if (b < 0) b += 8;
+    if (b >= 8) b -= 8;
+    atomicAdd(&patch[(y * 4 * 8) + (x * 8) + b], value);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectParams prm,
+                                                        const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
+                                                        const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
+                                                        float *__restrict__ desc_f32 /* may be null */) {
+    __shared__ float patch_all[4][DESC_N];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *patch = patch_all[wv];
+    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(desc_count[group], P.cap_desc[o]);
+    const int w = P.w[o], h = P.h[o];
+    const float delta = P.delta[o];
+    const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
+    const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
+    for (int di = blockIdx.x * 4 + wv; di < n; di += gridDim.x * 4) {
+        const DescInput in = desc_in[dbase + di];
+        const KeypointRec kp = kps[kbase + in.keypoint];
+        const float theta = in.theta;
+        const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // SIFTOctave.swift:417-418
+        const float *g = layer_ptr(P, frame, o, kp.scale);
+        const float px = (float)absoluteX / delta, py = (float)absoluteY / delta;   // metal :140-141
+        const int d = 4, bins = 8;
+        const float tau = 2.0f * SIFTMI_PI_F;
+        const float cosT = cosf(theta), sinT = sinf(theta);
+        const float binsPerRadian = (float)bins / tau;
+        const float exponentDenominator = (float)(d * d) * 0.5f;
+        const float interval = (float)kp.scale + kp.sub_scale;
+        const float intervals = (float)prm.desc_scales_per_octave;
+        const float sigma = 1.6f;
+        const float sc = sigma * powf(2.0f, interval / intervals);
+        const float histogramWidth = 3.0f * sc;
+        const int radius = (int)(histogramWidth * sqrtf(2.0f) * ((float)d + 1.0f) * 0.5f + 0.5f);
+
+        patch[lane] = 0.0f; patch[lane + 64] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        const int side = 2 * radius + 1, total = side * side;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int jj = idx / side, ii = idx - jj * side;
+            const int j = jj - radius, i = ii - radius;                   // j outer (x offset), i inner (y offset)
+            const float rx = ((float)j * cosT - (float)i * sinT) / histogramWidth;
+            const float ry = ((float)j * sinT + (float)i * cosT) / histogramWidth;
+            const float bx = rx + (float)(d / 2) - 0.5f;
+            const float by = ry + (float)(d / 2) - 0.5f;
+            const float fx = truncf(px + (float)j), fy = truncf(py + (float)i);   // ushort2(px + j, py + i)
+            float gth = 0.0f, gm = 0.0f;
+            if (fx >= 0.0f && fy >= 0.0f && fx < (float)w && fy < (float)h) gradient_at(g, w, h, (int)fx, (int)fy, gth, gm);
+            float orientation = gth - theta;
+            while (orientation < 0.0f) orientation += tau;
+            while (orientation >= tau) orientation -= tau;
+            const float bin = orientation * binsPerRadian;
+            const float exponentNumerator = rx * rx + ry * ry;
+            const float wgt = expf(-exponentNumerator / exponentDenominator);
+            const float value = gm * wgt;
+            {   // addFeature :82-117
+                const float flx = floorf(bx), fly = floorf(by), flb = floorf(bin);
+                const int cax = (int)flx, cay = (int)fly;
+                const int cbx = (int)ceilf(bx), ccy = (int)ceilf(by);
+                const int ba = (int)flb, bb = (int)ceilf(bin);
+                const float iMax = bx - flx, iMin = 1.0f - iMax;
+                const float jMax = by - fly, jMin = 1.0f - jMax;
+                const float bMax = bin - flb, bMin = 1.0f - bMax;
+                add_value(patch, cax, cay, ba, (iMin * jMin * bMin) * value);
+                add_value(patch, cax, cay, bb, (iMin * jMin * bMax) * value);
+                add_value(patch, cbx, cay, ba, (iMax * jMin * bMin) * value);
+                add_value(patch, cbx, cay, bb, (iMax * jMin * bMax) * value);
+                add_value(patch, cbx, ccy, ba, (iMax * jMax * bMin) * value);
+                add_value(patch, cbx, ccy, bb, (iMax * jMax * bMax) * value);
+                add_value(patch, cax, ccy, ba, (iMin * jMax * bMin) * value);
+                add_value(patch, cax, ccy, bb, (iMin * jMax * bMax) * value);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        float f0 = patch[lane], f1 = patch[lane + 64];
+        {   // normalise -> clamp 0.2 -> normalise (:15-39, :224-227)
+            float dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));
+            f0 *= dn; f1 *= dn;
+            f0 = fminf(f0, 0.2f); f1 = fminf(f1, 0.2f);
+            dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));
+            f0 *= dn; f1 *= dn;
+        }
+        DescriptorRec *out = desc_out + dbase + di;
+        out->features[lane] = (uint8_t)(int)fminf(255.0f, f0 * 512.0f);          // :42-50 truncation
+        out->features[lane + 64] = (uint8_t)(int)fminf(255.0f, f1 * 512.0f);
+        if (desc_f32) {
+            desc_f32[(dbase + di) * DESC_N + lane] = f0;
+            desc_f32[(dbase + di) * DESC_N + lane + 64] = f1;
+        }
+        if (lane == 0) { out->keypoint = in.keypoint; out->theta = theta; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packing: dense (frame, octave)-ordered output records + counts.  group_offsets_kernel is one
+// small workgroup; pack_kernel copies dwords.
+struct PackState {                 // device-resident running totals of a batch call
+    int32_t total_kp, total_desc, overflow_flags, pad;
+};
+
+__global__ __launch_bounds__(256) void group_offsets_kernel(PyramidDesc P, int n_frames, int frame_base, int total_frames,
+                                                           const int32_t *__restrict__ raw_count, const int32_t *__restrict__ cand_count,
+                                                           const int32_t *__restrict__ kp_count, const int32_t *__restrict__ oriented_count,
+                                                           const int32_t *__restrict__ desc_count,
+                                                           int32_t *__restrict__ kp_dst_off, int32_t *__restrict__ desc_dst_off,
+                                                           int32_t *__restrict__ out_counts /* [2][total_frames][n_oct] */,
+                                                           int32_t *__restrict__ stats /* [5][total_frames][n_oct] */,
+                                                           PackState *__restrict__ state, long long kp_capacity, long long desc_capacity) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int no = P.n_octaves, ng = n_frames * no;
+    int tk = state->total_kp, td = state->total_desc, flags = state->overflow_flags;
+    for (int g = 0; g < ng; g++) {
+        const int f = g / no, o = g - f * no;
+        int nk = kp_count[g], nd = desc_count[g];
+        if (cand_count[g] > P.cap_ext[o]) flags |= 1;
+        if (nk > P.cap_kp[o]) { flags |= 2; nk = P.cap_kp[o]; }
+        if (nd > P.cap_desc[o]) { flags |= 4; nd = P.cap_desc[o]; }
+        if ((long long)tk + nk > kp_capacity) { flags |= 8; nk = (int)max(0ll, kp_capacity - tk); }
+        if ((long long)td + nd > desc_capacity) { flags |= 16; nd = (int)max(0ll, desc_capacity - td); }
+        kp_dst_off[g] = tk; desc_dst_off[g] = td;
+        const int gi = (frame_base + f) * no + o, stride = total_frames * no;
+        out_counts[gi] = nk; out_counts[stride + gi] = nd;
+        stats[0 * stride + gi] = raw_count[g];
+        stats[1 * stride + gi] = cand_count[g];
+        stats[2 * stride + gi] = kp_count[g];
+        stats[3 * stride + gi] = oriented_count[g];
+        stats[4 * stride + gi] = desc_count[g];
+        tk += nk; td += nd;
+    }
+    state->total_kp = tk; state->total_desc = td; state->overflow_flags = flags;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(PyramidDesc P, const KeypointRec *__restrict__ kps, const DescriptorRec *__restrict__ descs,
+                                                  const int32_t *__restrict__ kp_dst_off, const int32_t *__restrict__ desc_dst_off,
+                                                  const int32_t *__restrict__ out_counts, int frame_base, int total_frames,
+                                                  KeypointRec *__restrict__ kp_out, DescriptorRec *__restrict__ desc_out) {
+    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int gi = (frame_base + frame) * P.n_octaves + o, stride = total_frames * P.n_octaves;
+    const int nk = out_counts[gi], nd = out_counts[stride + gi];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(kps + (size_t)frame * P.kp_frame + P.kp_off[o]);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(kp_out + kp_dst_off[group]);
+        const int nw = nk * (int)(sizeof(KeypointRec) / 4);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nw; i += gridDim.x * 256) dst[i] = src[i];
+    }
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(descs + (size_t)frame * P.desc_frame + P.desc_off[o]);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(desc_out + desc_dst_off[group]);
+        const long long nw = (long long)nd * (long long)(sizeof(DescriptorRec) / 4);
+        for (long long i = blockIdx.x * 256 + threadIdx.x; i < nw; i += gridDim.x * 256) dst[i] = src[i];
+    }
+}
+
+}  // namespace siftmi

@@ -1,0 +1,835 @@
+// siftmi_api.hip -- C ABI (include/siftmi.h) and host orchestration of the MI355X SIFT path.
+//
+// Host logic restated from the reference's Swift (never its code):
+//   schedule + weights   Sources/SIFTMetal/SIFT/DifferenceOfGaussians.swift:233-344, :69-147
+//                        Sources/SIFTMetal/Metal Compute/GaussianKernel.swift:20-43
+//   stage order          DifferenceOfGaussians.swift:346-406, SIFT/SIFT.swift:147-238,
+//                        SIFT/SIFTOctave.swift:177-492
+// Design differences (MI355X-first): frames are processed max_batch at a time in lock-step (one
+// launch per stage covers every frame), all lists and counters stay on the device, there is one
+// host synchronisation per call instead of 22 per frame, and only the Gaussian stack is
+// materialised in HBM (no DoG / gradient textures).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/siftmi.h"
+#include "dense_kernels.hip.h"
+#include "keypoint_kernels.hip.h"
+
+using namespace siftmi;
+
+static_assert(sizeof(KeypointRec) == sizeof(siftmi_keypoint) && sizeof(siftmi_keypoint) == 44, "keypoint layout");
+static_assert(sizeof(DescriptorRec) == sizeof(siftmi_descriptor) && sizeof(siftmi_descriptor) == 136, "descriptor layout");
+static_assert(sizeof(ExtremumRec) == sizeof(siftmi_extremum), "extremum layout");
+static_assert(sizeof(siftmi_descriptor_reference) == 524 && sizeof(siftmi_orientation) == 152, "reference layouts");
+
+static thread_local std::string g_last_error;
+static int set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return set_error(SIFTMI_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; int stage; };
+
+struct siftmi_ctx {
+    siftmi_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_oct = 0, nspo = 0, B = 1;
+    // schedule
+    int ow[MAX_OCT], oh[MAX_OCT];
+    float odelta[MAX_OCT];
+    float osigma[MAX_OCT][8];
+    int seed_taps = 0, taps[8];
+    TapWeights seed_w, layer_w[8];
+    // device memory
+    float *d_gauss = nullptr;
+    size_t frame_stride = 0;                  // floats
+    unsigned char *d_input = nullptr;         // staging for host frames
+    size_t input_bytes = 0;
+    ExtremumRec *d_ext = nullptr;
+    KeypointRec *d_kp_tmp = nullptr, *d_kp = nullptr;
+    unsigned long long *d_keys = nullptr;
+    int32_t *d_ori_count = nullptr;
+    float *d_ori_angles = nullptr;
+    DescInput *d_desc_in = nullptr;
+    DescriptorRec *d_desc = nullptr;
+    float *d_desc_f32 = nullptr;
+    int32_t *d_counters = nullptr;            // [5][B*n_oct]: raw, cand, kp, oriented, desc
+    int32_t *d_dst_off = nullptr;             // [2][B*n_oct]
+    PackState *d_state = nullptr;
+    // ctx-owned outputs (host-facing API)
+    KeypointRec *d_out_kp = nullptr; long long out_kp_cap = 0;
+    DescriptorRec *d_out_desc = nullptr; long long out_desc_cap = 0;
+    int32_t *d_out_counts = nullptr, *d_stats = nullptr; int out_frames_cap = 0;
+    // host mirrors
+    std::vector<siftmi_keypoint> h_kp;
+    std::vector<siftmi_descriptor> h_desc;
+    std::vector<int32_t> h_counts, h_stats;
+    int last_frames = 0;                      // frames of the last batch call
+    int last_sub_frames = 0;                  // frames resident in the pyramid
+    bool pyramid_valid = false;
+    PyramidDesc P;
+    DetectParams prm;
+    // timings
+    bool timing = false;
+    std::vector<EventPair> pending, pool;
+    double t_ms[SIFTMI_T_COUNT];
+    int64_t t_launches[SIFTMI_T_COUNT];
+};
+
+// ------------------------------------------------------------------------------------------------
+// GaussianKernel.swift:20-43 / GaussianSeriesKernel.swift:27-51
+static int gaussian_weights(float s, TapWeights &out) {
+    const int radius = (int)std::ceil(4.0f * s);
+    const int size = radius * 2 + 1;
+    if (size > 31) return -1;
+    float t = 0.0f;
+    const float ss = s * s;
+    for (int k = -radius, i = 0; k <= radius; k++, i++) {
+        const float kk = (float)(k * k);
+        const float w = std::exp(-0.5f * (kk / ss));
+        out.w[i] = w;
+        t += w;
+    }
+    for (int i = 0; i < size; i++) out.w[i] = out.w[i] / t;
+    for (int i = size; i < 32; i++) out.w[i] = 0.0f;
+    return size;
+}
+
+extern "C" int siftmi_default_config(siftmi_config *cfg, int32_t width, int32_t height) {
+    if (!cfg) return set_error(SIFTMI_E_BADARG, "cfg is null");
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->width = width; cfg->height = height;
+    cfg->n_octaves = 7;                 // DifferenceOfGaussians.swift:41
+    cfg->nspo = 3;                      // :46
+    cfg->sigma_min = 0.8f; cfg->delta_min = 0.5f; cfg->sigma_in = 0.5f;   // :28-37
+    cfg->dog_threshold = 0.0133f;       // SIFTOctave.swift:218
+    cfg->edge_threshold = 10.0f;        // :224
+    cfg->max_iterations = 5;            // :219
+    cfg->max_offset = 0.6f;             // :220
+    cfg->image_border = 5;              // SIFTInterpolate.metal:182
+    cfg->lambda_orientation = 1.5f;     // SIFTOctave.swift:298
+    cfg->orientation_threshold = 0.8f;  // :299
+    cfg->orientation_smoothing = 6;     // SIFTOrientation.metal:167
+    cfg->descriptor_scales_per_octave = 3;   // SIFTOctave.swift:398
+    cfg->full_neighbourhood = 0;
+    cfg->max_batch = 1;
+    return SIFTMI_OK;
+}
+
+extern "C" const char *siftmi_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int siftmi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static void free_ctx(siftmi_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_ori_count, c->d_ori_angles,
+                    c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_state, c->d_out_kp,
+                    c->d_out_desc, c->d_out_counts, c->d_stats};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void siftmi_destroy(siftmi_ctx *ctx) { free_ctx(ctx); }
+
+extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ctx **out) {
+    if (!cfg || !out) return set_error(SIFTMI_E_BADARG, "null argument");
+    *out = nullptr;
+    if (cfg->width < 1 || cfg->height < 1 || cfg->width > 32768 || cfg->height > 32768)
+        return set_error(SIFTMI_E_BADARG, "input size %dx%d out of range [1, 32768]", cfg->width, cfg->height);
+    if (cfg->n_octaves < 1 || cfg->n_octaves > SIFTMI_MAX_OCTAVES)
+        return set_error(SIFTMI_E_BADARG, "n_octaves %d out of range [1, %d]", cfg->n_octaves, SIFTMI_MAX_OCTAVES);
+    if (cfg->nspo < 1 || cfg->nspo > 5) return set_error(SIFTMI_E_BADARG, "nspo %d out of range [1, 5]", cfg->nspo);
+    if (cfg->delta_min != 0.5f) return set_error(SIFTMI_E_BADARG, "delta_min must be 0.5 (2x seed image)");
+    if (cfg->max_batch < 1 || cfg->max_batch > 4096) return set_error(SIFTMI_E_BADARG, "max_batch %d out of range", cfg->max_batch);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(SIFTMI_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (hip_device < 0 || hip_device >= ndev) return set_error(SIFTMI_E_BADARG, "hip_device %d out of range [0, %d)", hip_device, ndev);
+
+    siftmi_ctx *c = new siftmi_ctx();
+    c->cfg = *cfg;
+    c->device = hip_device;
+    c->n_oct = cfg->n_octaves; c->nspo = cfg->nspo; c->B = cfg->max_batch;
+    memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_launches, 0, sizeof(c->t_launches));
+    const int W = cfg->width, H = cfg->height, nspo = cfg->nspo, NG = nspo + 3;
+
+    // --- schedule: DifferenceOfGaussians.swift:235-238, 255-262, 315-328, Octave.init :91-102
+    {
+        const float i = cfg->sigma_min * cfg->sigma_min, j = cfg->sigma_in * cfg->sigma_in;
+        const float k = std::sqrt(i - j) / cfg->delta_min;
+        c->seed_taps = gaussian_weights(k, c->seed_w);
+        if (c->seed_taps < 0) { free_ctx(c); return set_error(SIFTMI_E_BADARG, "seed blur needs more than 31 taps"); }
+    }
+    size_t off = 0, ext_off = 0, kp_off = 0, desc_off = 0;
+    memset(&c->P, 0, sizeof(c->P));
+    for (int o = 0; o < c->n_oct; o++) {
+        const float delta = cfg->delta_min * std::pow(2.0f, (float)o);
+        c->odelta[o] = delta;
+        c->ow[o] = (int)((float)W / delta);
+        c->oh[o] = (int)((float)H / delta);
+        if (c->ow[o] < 1 || c->oh[o] < 1) {
+            free_ctx(c);
+            return set_error(SIFTMI_E_BADARG, "octave %d of a %dx%d input is empty; use at most %d octaves", o, W, H, o);
+        }
+        for (int s = 0; s < NG; s++) {
+            const float hh = delta / cfg->delta_min;
+            const float ii = (float)s / (float)nspo;
+            const float jj = std::pow(2.0f, ii);
+            c->osigma[o][s] = hh * cfg->sigma_min * jj;
+        }
+        if (o == 0) {
+            for (int s = 1; s < NG; s++) {
+                const float sa = c->osigma[0][s - 1], sb = c->osigma[0][s];
+                const float rho = std::sqrt(sb * sb - sa * sa) / delta;
+                c->taps[s - 1] = gaussian_weights(rho, c->layer_w[s - 1]);
+                if (c->taps[s - 1] < 0) { free_ctx(c); return set_error(SIFTMI_E_BADARG, "layer %d blur needs more than 31 taps", s); }
+            }
+        }
+        const size_t n = (size_t)c->ow[o] * c->oh[o];
+        c->P.oct_offset[o] = off;
+        off += (n * NG + 3) & ~(size_t)3;
+        c->P.w[o] = c->ow[o]; c->P.h[o] = c->oh[o]; c->P.delta[o] = delta;
+        c->P.sigma0[o] = c->osigma[o][0]; c->P.sigma1[o] = c->osigma[o][1];
+        for (int s = 0; s < NG; s++) c->P.sigmas[o][s] = c->osigma[o][s];
+        auto clampi = [](long long v, long long lo, long long hi) { return (int)std::max(lo, std::min(hi, v)); };
+        c->P.cap_ext[o] = cfg->max_extrema > 0 ? cfg->max_extrema : clampi((long long)n / 32, 4096, 1 << 20);
+        c->P.cap_kp[o] = cfg->max_keypoints > 0 ? cfg->max_keypoints : clampi((long long)n / 64, 4096, 1 << 19);
+        c->P.cap_desc[o] = cfg->max_descriptors > 0 ? cfg->max_descriptors : (c->P.cap_kp[o] + c->P.cap_kp[o] / 2);
+        c->P.ext_off[o] = ext_off; ext_off += c->P.cap_ext[o];
+        c->P.kp_off[o] = kp_off; kp_off += c->P.cap_kp[o];
+        c->P.desc_off[o] = desc_off; desc_off += c->P.cap_desc[o];
+    }
+    c->frame_stride = off;
+    c->P.frame_stride = off; c->P.n_octaves = c->n_oct; c->P.nspo = nspo;
+    c->P.ext_frame = ext_off; c->P.kp_frame = kp_off; c->P.desc_frame = desc_off;
+    c->prm.dog_threshold = cfg->dog_threshold; c->prm.edge_threshold = cfg->edge_threshold;
+    c->prm.max_offset = cfg->max_offset; c->prm.max_iterations = cfg->max_iterations;
+    c->prm.border = cfg->image_border; c->prm.full_neighbourhood = cfg->full_neighbourhood;
+    c->prm.lambda_ori = cfg->lambda_orientation; c->prm.ori_threshold = cfg->orientation_threshold;
+    c->prm.ori_smoothing = cfg->orientation_smoothing; c->prm.desc_scales_per_octave = cfg->descriptor_scales_per_octave;
+
+    hipError_t e = hipSetDevice(hip_device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    const size_t B = (size_t)c->B, G = B * c->n_oct;
+    auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 16)); };
+    alloc((void **)&c->d_gauss, B * off * sizeof(float));
+    c->input_bytes = (size_t)W * H * 4;
+    alloc((void **)&c->d_input, B * c->input_bytes);
+    alloc((void **)&c->d_ext, B * ext_off * sizeof(ExtremumRec));
+    alloc((void **)&c->d_kp_tmp, B * kp_off * sizeof(KeypointRec));
+    alloc((void **)&c->d_kp, B * kp_off * sizeof(KeypointRec));
+    alloc((void **)&c->d_keys, B * kp_off * sizeof(unsigned long long));
+    alloc((void **)&c->d_ori_count, B * kp_off * sizeof(int32_t));
+    alloc((void **)&c->d_ori_angles, B * kp_off * ORI_BINS * sizeof(float));
+    alloc((void **)&c->d_desc_in, B * desc_off * sizeof(DescInput));
+    alloc((void **)&c->d_desc, B * desc_off * sizeof(DescriptorRec));
+    if (cfg->keep_descriptor_floats) alloc((void **)&c->d_desc_f32, B * desc_off * DESC_N * sizeof(float));
+    alloc((void **)&c->d_counters, 5 * G * sizeof(int32_t));
+    alloc((void **)&c->d_dst_off, 2 * G * sizeof(int32_t));
+    alloc((void **)&c->d_state, sizeof(PackState));
+    if (e != hipSuccess) {
+        const int code = (e == hipErrorOutOfMemory) ? SIFTMI_E_NOMEM : SIFTMI_E_HIP;
+        set_error(code, "context allocation failed: %s", hipGetErrorString(e));
+        free_ctx(c);
+        return code;
+    }
+    c->P.gauss = c->d_gauss;
+    *out = c;
+    return SIFTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timing helpers
+static void t_begin(siftmi_ctx *c, int stage) {
+    if (!c->timing) return;
+    EventPair ep;
+    if (!c->pool.empty()) { ep = c->pool.back(); c->pool.pop_back(); }
+    else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
+    ep.stage = stage;
+    (void)hipEventRecord(ep.a, c->stream);
+    c->pending.push_back(ep);
+}
+static void t_end(siftmi_ctx *c) {
+    if (!c->timing) return;
+    (void)hipEventRecord(c->pending.back().b, c->stream);
+}
+static void t_collect(siftmi_ctx *c) {
+    for (auto &ep : c->pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            c->t_ms[ep.stage] += ms;
+            c->t_launches[ep.stage] += 1;
+        }
+        c->pool.push_back(ep);
+    }
+    c->pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+template <int R, bool SEED>
+static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
+                                const TapWeights &wt, const SeedSource &seed) {
+    using Gm = BlurGeom<R>;
+    dim3 grid((w + Gm::TW - 1) / Gm::TW, (h + Gm::TH - 1) / Gm::TH, nf);
+    hipLaunchKernelGGL((blur_layer_kernel<R, SEED>), grid, dim3(256), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
+                       c->frame_stride, wt, seed);
+    return hipGetLastError();
+}
+
+template <bool SEED>
+static hipError_t launch_blur(siftmi_ctx *c, hipStream_t st, int radius, const float *src, float *dst, int w, int h, int nf,
+                              const TapWeights &wt, const SeedSource &seed) {
+    switch (radius) {
+#define CASE_R(r) case r: return launch_blur_r<r, SEED>(c, st, src, dst, w, h, nf, wt, seed);
+        CASE_R(1) CASE_R(2) CASE_R(3) CASE_R(4) CASE_R(5) CASE_R(6) CASE_R(7) CASE_R(8)
+        CASE_R(9) CASE_R(10) CASE_R(11) CASE_R(12) CASE_R(13) CASE_R(14) CASE_R(15)
+#undef CASE_R
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static float *gauss_ptr(siftmi_ctx *c, int o, int s) {
+    return c->d_gauss + c->P.oct_offset[o] + (size_t)s * c->ow[o] * c->oh[o];
+}
+
+// dense front end for nf frames: seed -> per-octave layer blurs (DifferenceOfGaussians.swift:346-406)
+static int run_dense(siftmi_ctx *c, hipStream_t st, int nf, const void *d_pixels, int format, size_t row_stride, size_t frame_stride) {
+    const int NG = c->nspo + 3;
+    SeedSource seed;
+    seed.pixels = (const unsigned char *)d_pixels; seed.frame_stride = frame_stride; seed.row_stride = row_stride;
+    seed.format = format; seed.in_w = c->cfg.width; seed.in_h = c->cfg.height;
+    SeedSource none; memset(&none, 0, sizeof(none));
+    t_begin(c, SIFTMI_T_SEED);
+    HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed)));
+    t_end(c);
+    for (int o = 0; o < c->n_oct; o++) {
+        if (o > 0) {
+            t_begin(c, SIFTMI_T_DOWNSAMPLE);
+            dim3 grid((c->ow[o] + 63) / 64, (c->oh[o] + 3) / 4, nf);
+            hipLaunchKernelGGL(downsample_kernel, grid, dim3(256), 0, st, gauss_ptr(c, o - 1, c->nspo), gauss_ptr(c, o, 0),
+                               c->ow[o - 1], c->oh[o - 1], c->ow[o], c->oh[o], c->frame_stride, c->frame_stride);
+            HIP_TRY(hipGetLastError());
+            t_end(c);
+        }
+        for (int s = 1; s < NG; s++) {
+            t_begin(c, SIFTMI_T_BLUR);
+            HIP_TRY((launch_blur<false>(c, st, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
+                                        nf, c->layer_w[s - 1], none)));
+            t_end(c);
+        }
+    }
+    return SIFTMI_OK;
+}
+
+static int32_t *cnt(siftmi_ctx *c, int which) { return c->d_counters + (size_t)which * c->B * c->n_oct; }
+enum { C_RAW = 0, C_CAND = 1, C_KP = 2, C_ORIENTED = 3, C_DESC = 4 };
+
+// extrema -> refine -> sort  (SIFT.swift:147-202)
+static int run_detect(siftmi_ctx *c, hipStream_t st, int nf) {
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 5 * (size_t)c->B * c->n_oct * sizeof(int32_t), st));
+    const int EH = 16;
+    for (int o = 0; o < c->n_oct; o++) {
+        if (c->ow[o] < 3 || c->oh[o] < 3) continue;
+        t_begin(c, SIFTMI_T_EXTREMA);
+        dim3 grid((c->ow[o] + 255) / 256, (c->oh[o] - 2 + EH - 1) / EH, nf);
+#define LAUNCH_EXT(NS) hipLaunchKernelGGL((extrema_kernel<NS>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW))
+        switch (c->nspo) {
+            case 1: LAUNCH_EXT(1); break;
+            case 2: LAUNCH_EXT(2); break;
+            case 3: LAUNCH_EXT(3); break;
+            case 4: LAUNCH_EXT(4); break;
+            default: LAUNCH_EXT(5); break;
+        }
+#undef LAUNCH_EXT
+        HIP_TRY(hipGetLastError());
+        t_end(c);
+    }
+    const int groups = nf * c->n_oct;
+    t_begin(c, SIFTMI_T_REFINE);
+    hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
+                       cnt(c, C_KP));
+    HIP_TRY(hipGetLastError());
+    t_end(c);
+    t_begin(c, SIFTMI_T_SORT);
+    hipLaunchKernelGGL(sort_keypoints_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_keys, cnt(c, C_KP), c->d_kp);
+    HIP_TRY(hipGetLastError());
+    t_end(c);
+    return SIFTMI_OK;
+}
+
+// orientation -> expansion -> descriptors  (SIFT.swift:207-238)
+static int run_describe(siftmi_ctx *c, hipStream_t st, int nf) {
+    const int groups = nf * c->n_oct;
+    t_begin(c, SIFTMI_T_ORIENT);
+    hipLaunchKernelGGL(orientation_kernel, dim3(256, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+                       c->d_ori_angles);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(expand_descriptors_kernel, dim3(groups), dim3(1024), 0, st, c->P, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
+                       c->d_desc_in, cnt(c, C_DESC), cnt(c, C_ORIENTED));
+    HIP_TRY(hipGetLastError());
+    t_end(c);
+    t_begin(c, SIFTMI_T_DESCRIBE);
+    hipLaunchKernelGGL(descriptor_kernel, dim3(256, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+                       c->d_desc_f32);
+    HIP_TRY(hipGetLastError());
+    t_end(c);
+    return SIFTMI_OK;
+}
+
+static int run_pack(siftmi_ctx *c, hipStream_t st, int nf, int frame_base, int total_frames, KeypointRec *kp_out, long long kp_cap,
+                    DescriptorRec *desc_out, long long desc_cap, int32_t *d_counts, int32_t *d_stats) {
+    const int groups = nf * c->n_oct;
+    t_begin(c, SIFTMI_T_PACK);
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(64), 0, st, c->P, nf, frame_base, total_frames, cnt(c, C_RAW), cnt(c, C_CAND),
+                       cnt(c, C_KP), cnt(c, C_ORIENTED), cnt(c, C_DESC), c->d_dst_off, c->d_dst_off + (size_t)c->B * c->n_oct, d_counts,
+                       d_stats, c->d_state, kp_cap, desc_cap);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pack_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp, c->d_desc, c->d_dst_off,
+                       c->d_dst_off + (size_t)c->B * c->n_oct, d_counts, frame_base, total_frames, kp_out, desc_out);
+    HIP_TRY(hipGetLastError());
+    t_end(c);
+    return SIFTMI_OK;
+}
+
+static int ensure_stats(siftmi_ctx *c, int n_frames) {
+    if (n_frames <= c->out_frames_cap) return SIFTMI_OK;
+    if (c->d_out_counts) (void)hipFree(c->d_out_counts);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    c->d_out_counts = nullptr; c->d_stats = nullptr; c->out_frames_cap = 0;
+    HIP_TRY(hipMalloc((void **)&c->d_out_counts, 2 * (size_t)n_frames * c->n_oct * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_stats, 5 * (size_t)n_frames * c->n_oct * sizeof(int32_t)));
+    c->out_frames_cap = n_frames;
+    return SIFTMI_OK;
+}
+
+static int check_format(siftmi_ctx *c, int format, size_t row_stride) {
+    const size_t bpp = format == SIFTMI_FMT_BGRA8 ? 4 : format == SIFTMI_FMT_GRAY8 ? 1 : format == SIFTMI_FMT_GRAYF32 ? 4 : 0;
+    if (!bpp) return set_error(SIFTMI_E_BADARG, "unknown pixel format %d", format);
+    if (row_stride < bpp * (size_t)c->cfg.width) return set_error(SIFTMI_E_BADARG, "row_stride %zu smaller than a row", row_stride);
+    if ((format == SIFTMI_FMT_BGRA8 || format == SIFTMI_FMT_GRAYF32) && (row_stride & 3))
+        return set_error(SIFTMI_E_BADARG, "row_stride must be a multiple of 4 for this format");
+    return SIFTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_frames, const void *d_pixels, int format, size_t row_stride,
+                                                   size_t frame_stride, siftmi_keypoint *d_keypoints, int64_t kp_capacity,
+                                                   siftmi_descriptor *d_descriptors, int64_t desc_capacity, int32_t *d_counts,
+                                                   int32_t *d_totals, void *stream) {
+    if (!c || !d_pixels || !d_keypoints || !d_descriptors || !d_counts) return set_error(SIFTMI_E_BADARG, "null argument");
+    if (n_frames < 1) return set_error(SIFTMI_E_BADARG, "n_frames must be >= 1");
+    int rc = check_format(c, format, row_stride);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    rc = ensure_stats(c, n_frames);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
+    for (int f0 = 0; f0 < n_frames; f0 += c->B) {
+        const int nf = std::min(c->B, n_frames - f0);
+        const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
+        if ((rc = run_dense(c, st, nf, px, format, row_stride, frame_stride))) return rc;
+        if ((rc = run_detect(c, st, nf))) return rc;
+        if ((rc = run_describe(c, st, nf))) return rc;
+        if ((rc = run_pack(c, st, nf, f0, n_frames, (KeypointRec *)d_keypoints, kp_capacity, (DescriptorRec *)d_descriptors, desc_capacity,
+                           d_counts, c->d_stats)))
+            return rc;
+        c->last_sub_frames = nf;
+    }
+    if (d_totals) HIP_TRY(hipMemcpyAsync(d_totals, c->d_state, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    c->last_frames = n_frames;
+    c->pyramid_valid = true;
+    return SIFTMI_OK;
+}
+
+static int grow_outputs(siftmi_ctx *c, long long kp_need, long long desc_need) {
+    if (kp_need > c->out_kp_cap) {
+        if (c->d_out_kp) (void)hipFree(c->d_out_kp);
+        c->d_out_kp = nullptr; c->out_kp_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_out_kp, (size_t)kp_need * sizeof(KeypointRec)));
+        c->out_kp_cap = kp_need;
+    }
+    if (desc_need > c->out_desc_cap) {
+        if (c->d_out_desc) (void)hipFree(c->d_out_desc);
+        c->d_out_desc = nullptr; c->out_desc_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_out_desc, (size_t)desc_need * sizeof(DescriptorRec)));
+        c->out_desc_cap = desc_need;
+    }
+    return SIFTMI_OK;
+}
+
+static int overflow_error(siftmi_ctx *c, int flags) {
+    std::string what;
+    if (flags & 1) what += " extrema(max_extrema)";
+    if (flags & 2) what += " keypoints(max_keypoints)";
+    if (flags & 4) what += " descriptors(max_descriptors)";
+    if (flags & 8) what += " keypoint-output";
+    if (flags & 16) what += " descriptor-output";
+    int32_t mx[5] = {0, 0, 0, 0, 0};
+    const size_t stride = (size_t)c->last_frames * c->n_oct;
+    for (int k = 0; k < 5; k++)
+        for (size_t i = 0; i < stride && (k * stride + i) < c->h_stats.size(); i++) mx[k] = std::max(mx[k], c->h_stats[k * stride + i]);
+    return set_error(SIFTMI_E_CAPACITY, "list capacity exceeded:%s; largest per-(frame,octave) counts: candidates %d keypoints %d descriptors %d",
+                     what.c_str(), mx[1], mx[2], mx[4]);
+}
+
+// stage frames from the host (or accept a device pointer) and return the device view
+static int stage_input(siftmi_ctx *c, int nf, const void *pixels, int format, size_t row_stride, size_t frame_stride, int on_device,
+                       const void **d_px, size_t *d_row, size_t *d_frame) {
+    if (on_device) { *d_px = pixels; *d_row = row_stride; *d_frame = frame_stride; return SIFTMI_OK; }
+    const size_t bpp = format == SIFTMI_FMT_GRAY8 ? 1 : 4;
+    const size_t row = bpp * (size_t)c->cfg.width;
+    const size_t fr = row * c->cfg.height;
+    for (int f = 0; f < nf; f++)
+        HIP_TRY(hipMemcpy2DAsync(c->d_input + (size_t)f * c->input_bytes, row, (const unsigned char *)pixels + (size_t)f * frame_stride,
+                                 row_stride, row, c->cfg.height, hipMemcpyHostToDevice, c->stream));
+    (void)fr;
+    *d_px = c->d_input; *d_row = row; *d_frame = c->input_bytes;
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, const void *pixels, int format, size_t row_stride,
+                                            size_t frame_stride, int on_device, const siftmi_keypoint **keypoints,
+                                            const int32_t **kp_counts, const siftmi_descriptor **descriptors, const int32_t **desc_counts) {
+    if (!c || !pixels) return set_error(SIFTMI_E_BADARG, "null argument");
+    if (n_frames < 1) return set_error(SIFTMI_E_BADARG, "n_frames must be >= 1");
+    int rc = check_format(c, format, row_stride);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    long long kp_need = 0, desc_need = 0;
+    for (int o = 0; o < c->n_oct; o++) { kp_need += c->P.cap_kp[o]; desc_need += c->P.cap_desc[o]; }
+    kp_need = std::min<long long>(kp_need, 1 << 17) * n_frames;
+    desc_need = std::min<long long>(desc_need, 3 << 16) * n_frames;
+    if ((rc = grow_outputs(c, kp_need, desc_need))) return rc;
+    if ((rc = ensure_stats(c, n_frames))) return rc;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
+    for (int f0 = 0; f0 < n_frames; f0 += c->B) {
+        const int nf = std::min(c->B, n_frames - f0);
+        const void *d_px; size_t d_row, d_frame;
+        const unsigned char *src = (const unsigned char *)pixels + (size_t)f0 * frame_stride;
+        if ((rc = stage_input(c, nf, src, format, row_stride, frame_stride, on_device, &d_px, &d_row, &d_frame))) return rc;
+        if ((rc = run_dense(c, st, nf, d_px, format, d_row, d_frame))) return rc;
+        if ((rc = run_detect(c, st, nf))) return rc;
+        if ((rc = run_describe(c, st, nf))) return rc;
+        if ((rc = run_pack(c, st, nf, f0, n_frames, c->d_out_kp, c->out_kp_cap, c->d_out_desc, c->out_desc_cap, c->d_out_counts, c->d_stats)))
+            return rc;
+        c->last_sub_frames = nf;
+    }
+    PackState ps;
+    HIP_TRY(hipMemcpyAsync(&ps, c->d_state, sizeof(ps), hipMemcpyDeviceToHost, st));
+    const size_t ng = (size_t)n_frames * c->n_oct;
+    c->h_counts.resize(2 * ng); c->h_stats.resize(5 * ng);
+    HIP_TRY(hipMemcpyAsync(c->h_counts.data(), c->d_out_counts, 2 * ng * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_stats.data(), c->d_stats, 5 * ng * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->h_kp.resize((size_t)std::max(ps.total_kp, 1)); c->h_desc.resize((size_t)std::max(ps.total_desc, 1));
+    if (ps.total_kp) HIP_TRY(hipMemcpyAsync(c->h_kp.data(), c->d_out_kp, (size_t)ps.total_kp * sizeof(KeypointRec), hipMemcpyDeviceToHost, st));
+    if (ps.total_desc) HIP_TRY(hipMemcpyAsync(c->h_desc.data(), c->d_out_desc, (size_t)ps.total_desc * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    t_collect(c);
+    c->last_frames = n_frames;
+    c->pyramid_valid = true;
+    if (keypoints) *keypoints = c->h_kp.data();
+    if (kp_counts) *kp_counts = c->h_counts.data();
+    if (descriptors) *descriptors = c->h_desc.data();
+    if (desc_counts) *desc_counts = c->h_counts.data() + ng;
+    if (ps.overflow_flags) return overflow_error(c, ps.overflow_flags);
+    return SIFTMI_OK;
+}
+
+// SIFT.getKeypoints (SIFT.swift:147-152): one frame, detection only; the pyramid stays resident.
+extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size_t row_stride, int on_device,
+                             const siftmi_keypoint **keypoints, int32_t *counts) {
+    if (!c || !pixels || !counts) return set_error(SIFTMI_E_BADARG, "null argument");
+    int rc = check_format(c, format, row_stride);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const void *d_px; size_t d_row, d_frame;
+    if ((rc = stage_input(c, 1, pixels, format, row_stride, 0, on_device, &d_px, &d_row, &d_frame))) return rc;
+    if ((rc = run_dense(c, st, 1, d_px, format, d_row, d_frame))) return rc;
+    if ((rc = run_detect(c, st, 1))) return rc;
+    std::vector<int32_t> h(5 * (size_t)c->B * c->n_oct);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->d_counters, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t cs = (size_t)c->B * c->n_oct;
+    int flags = 0;
+    size_t total = 0;
+    c->h_stats.assign(5 * (size_t)c->n_oct, 0);
+    for (int o = 0; o < c->n_oct; o++) {
+        if (h[C_CAND * cs + o] > c->P.cap_ext[o]) flags |= 1;
+        int nk = h[C_KP * cs + o];
+        if (nk > c->P.cap_kp[o]) { flags |= 2; nk = c->P.cap_kp[o]; }
+        counts[o] = nk;
+        total += nk;
+        for (int k = 0; k < 3; k++) c->h_stats[(size_t)k * c->n_oct + o] = h[k * cs + o];
+    }
+    c->h_kp.resize(std::max<size_t>(total, 1));
+    size_t pos = 0;
+    for (int o = 0; o < c->n_oct; o++) {
+        if (counts[o]) HIP_TRY(hipMemcpyAsync(c->h_kp.data() + pos, c->d_kp + c->P.kp_off[o], (size_t)counts[o] * sizeof(KeypointRec), hipMemcpyDeviceToHost, st));
+        pos += counts[o];
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    t_collect(c);
+    c->last_frames = 1; c->last_sub_frames = 1; c->pyramid_valid = true;
+    if (keypoints) *keypoints = c->h_kp.data();
+    if (flags) return overflow_error(c, flags);
+    return SIFTMI_OK;
+}
+
+// SIFT.getDescriptors (SIFT.swift:207-238): keypoints (possibly filtered by the caller) in, descriptors out
+extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, const int32_t *counts,
+                               const siftmi_descriptor **descriptors, int32_t *desc_counts) {
+    if (!c || !counts || !desc_counts) return set_error(SIFTMI_E_BADARG, "null argument");
+    if (!c->pyramid_valid) return set_error(SIFTMI_E_STATE, "siftmi_describe needs a preceding siftmi_detect on this context");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t cs = (size_t)c->B * c->n_oct;
+    std::vector<int32_t> h(cs, 0);
+    size_t pos = 0;
+    for (int o = 0; o < c->n_oct; o++) {
+        if (counts[o] < 0 || counts[o] > c->P.cap_kp[o])
+            return set_error(SIFTMI_E_CAPACITY, "octave %d: %d keypoints exceed max_keypoints %d", o, counts[o], c->P.cap_kp[o]);
+        if (counts[o] && !keypoints) return set_error(SIFTMI_E_BADARG, "keypoints is null");
+        for (int k = 0; k < counts[o]; k++) {
+            const siftmi_keypoint &kp = keypoints[pos + k];
+            if (kp.scale < 0 || kp.scale >= c->nspo + 3 || !(kp.sigma > 0.0f))
+                return set_error(SIFTMI_E_BADARG, "octave %d keypoint %d: scale %d / sigma %g invalid", o, k, kp.scale, (double)kp.sigma);
+        }
+        if (counts[o]) HIP_TRY(hipMemcpyAsync(c->d_kp + c->P.kp_off[o], keypoints + pos, (size_t)counts[o] * sizeof(KeypointRec), hipMemcpyHostToDevice, st));
+        h[o] = counts[o];
+        pos += counts[o];
+    }
+    HIP_TRY(hipMemcpyAsync(cnt(c, C_KP), h.data(), cs * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(cnt(c, C_ORIENTED), 0, 2 * cs * sizeof(int32_t), st));
+    int rc;
+    if ((rc = run_describe(c, st, 1))) return rc;
+    std::vector<int32_t> hc(5 * cs);
+    HIP_TRY(hipMemcpyAsync(hc.data(), c->d_counters, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int flags = 0;
+    size_t total = 0;
+    if (c->h_stats.size() != 5 * (size_t)c->n_oct) c->h_stats.assign(5 * (size_t)c->n_oct, 0);
+    for (int o = 0; o < c->n_oct; o++) {
+        int nd = hc[C_DESC * cs + o];
+        if (nd > c->P.cap_desc[o]) { flags |= 4; nd = c->P.cap_desc[o]; }
+        desc_counts[o] = nd;
+        total += nd;
+        c->h_stats[(size_t)2 * c->n_oct + o] = counts[o];
+        c->h_stats[(size_t)3 * c->n_oct + o] = hc[C_ORIENTED * cs + o];
+        c->h_stats[(size_t)4 * c->n_oct + o] = hc[C_DESC * cs + o];
+    }
+    c->h_desc.resize(std::max<size_t>(total, 1));
+    pos = 0;
+    for (int o = 0; o < c->n_oct; o++) {
+        if (desc_counts[o]) HIP_TRY(hipMemcpyAsync(c->h_desc.data() + pos, c->d_desc + c->P.desc_off[o], (size_t)desc_counts[o] * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
+        pos += desc_counts[o];
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    t_collect(c);
+    c->last_frames = 1;
+    if (descriptors) *descriptors = c->h_desc.data();
+    if (flags) return overflow_error(c, flags);
+    return SIFTMI_OK;
+}
+
+extern "C" void siftmi_descriptor_to_reference(const siftmi_descriptor *in, int64_t n, siftmi_descriptor_reference *out) {
+    for (int64_t i = 0; i < n; i++) {
+        out[i].valid = 1;
+        out[i].keypoint = in[i].keypoint;
+        out[i].theta = in[i].theta;
+        for (int k = 0; k < SIFTMI_DESCRIPTOR_FEATURES; k++) out[i].features[k] = in[i].features[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// introspection
+extern "C" int siftmi_get_stats(siftmi_ctx *c, siftmi_stats *out) {
+    if (!c || !out) return set_error(SIFTMI_E_BADARG, "null argument");
+    const size_t ng = (size_t)c->last_frames * c->n_oct;
+    if (c->h_stats.size() < 5 * ng || ng == 0) return set_error(SIFTMI_E_STATE, "no statistics yet");
+    out->n_frames = c->last_frames; out->n_octaves = c->n_oct;
+    out->raw_extrema = c->h_stats.data(); out->candidates = c->h_stats.data() + ng; out->keypoints = c->h_stats.data() + 2 * ng;
+    out->oriented = c->h_stats.data() + 3 * ng; out->descriptors = c->h_stats.data() + 4 * ng;
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_octave_size(siftmi_ctx *c, int o, int32_t *w, int32_t *h, float *delta) {
+    if (!c || o < 0 || o >= c->n_oct) return set_error(SIFTMI_E_BADARG, "bad octave");
+    if (w) *w = c->ow[o];
+    if (h) *h = c->oh[o];
+    if (delta) *delta = c->odelta[o];
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_get_sigma(siftmi_ctx *c, int o, int s, float *sigma) {
+    if (!c || !sigma || o < 0 || o >= c->n_oct || s < 0 || s >= c->nspo + 3) return set_error(SIFTMI_E_BADARG, "bad octave/scale");
+    *sigma = c->osigma[o][s];
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_get_weights(siftmi_ctx *c, int layer, float *weights, int32_t *count) {
+    if (!c || !count || layer < 0 || layer > c->nspo + 2) return set_error(SIFTMI_E_BADARG, "bad layer");
+    const int n = layer == 0 ? c->seed_taps : c->taps[layer - 1];
+    const TapWeights &w = layer == 0 ? c->seed_w : c->layer_w[layer - 1];
+    if (weights) memcpy(weights, w.w, sizeof(float) * (size_t)n);
+    *count = n;
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_copy_gaussian(siftmi_ctx *c, int frame, int o, int s, float *dst) {
+    if (!c || !dst || o < 0 || o >= c->n_oct || s < 0 || s >= c->nspo + 3 || frame < 0 || frame >= c->B)
+        return set_error(SIFTMI_E_BADARG, "bad frame/octave/layer");
+    if (!c->pyramid_valid) return set_error(SIFTMI_E_STATE, "no pyramid resident");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(dst, gauss_ptr(c, o, s) + (size_t)frame * c->frame_stride, (size_t)c->ow[o] * c->oh[o] * sizeof(float), hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+static int read_counter(siftmi_ctx *c, int which, int frame, int o, int32_t *v) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(v, cnt(c, which) + (size_t)frame * c->n_oct + o, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_copy_extrema(siftmi_ctx *c, int frame, int o, siftmi_extremum *dst, int32_t cap, int32_t *count) {
+    if (!c || !count || o < 0 || o >= c->n_oct || frame < 0 || frame >= c->B) return set_error(SIFTMI_E_BADARG, "bad frame/octave");
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t n = 0;
+    int rc = read_counter(c, C_CAND, frame, o, &n);
+    if (rc) return rc;
+    *count = n;
+    const int m = std::min(std::min(n, cap), c->P.cap_ext[o]);
+    if (dst && m > 0) {
+        HIP_TRY(hipMemcpy(dst, c->d_ext + (size_t)frame * c->P.ext_frame + c->P.ext_off[o], (size_t)m * sizeof(ExtremumRec), hipMemcpyDeviceToHost));
+        std::sort(dst, dst + m, [](const siftmi_extremum &a, const siftmi_extremum &b) {
+            if (a.scale != b.scale) return a.scale < b.scale;
+            if (a.y != b.y) return a.y < b.y;
+            return a.x < b.x;
+        });
+    }
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_copy_orientations(siftmi_ctx *c, int frame, int o, siftmi_orientation *dst, int32_t cap, int32_t *count) {
+    if (!c || !count || o < 0 || o >= c->n_oct || frame < 0 || frame >= c->B) return set_error(SIFTMI_E_BADARG, "bad frame/octave");
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t n = 0;
+    int rc = read_counter(c, C_KP, frame, o, &n);
+    if (rc) return rc;
+    n = std::min(n, c->P.cap_kp[o]);
+    *count = n;
+    const int m = std::min(n, cap);
+    if (dst && m > 0) {
+        std::vector<int32_t> oc(m);
+        std::vector<float> oa((size_t)m * ORI_BINS);
+        const size_t base = (size_t)frame * c->P.kp_frame + c->P.kp_off[o];
+        HIP_TRY(hipMemcpy(oc.data(), c->d_ori_count + base, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(oa.data(), c->d_ori_angles + base * ORI_BINS, (size_t)m * ORI_BINS * sizeof(float), hipMemcpyDeviceToHost));
+        for (int k = 0; k < m; k++) {
+            dst[k].keypoint = k; dst[k].count = oc[k];
+            for (int t = 0; t < ORI_BINS; t++) dst[k].orientations[t] = (t < oc[k]) ? oa[(size_t)k * ORI_BINS + t] : 0.0f;
+        }
+    }
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_copy_descriptor_floats(siftmi_ctx *c, int frame, int o, float *dst, int32_t cap, int32_t *count) {
+    if (!c || !count || o < 0 || o >= c->n_oct || frame < 0 || frame >= c->B) return set_error(SIFTMI_E_BADARG, "bad frame/octave");
+    if (!c->d_desc_f32) return set_error(SIFTMI_E_STATE, "context was created without keep_descriptor_floats");
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t n = 0;
+    int rc = read_counter(c, C_DESC, frame, o, &n);
+    if (rc) return rc;
+    n = std::min(n, c->P.cap_desc[o]);
+    *count = n;
+    const int m = std::min(n, cap);
+    if (dst && m > 0)
+        HIP_TRY(hipMemcpy(dst, c->d_desc_f32 + ((size_t)frame * c->P.desc_frame + c->P.desc_off[o]) * DESC_N, (size_t)m * DESC_N * sizeof(float), hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timing
+extern "C" int siftmi_enable_timings(siftmi_ctx *c, int enable) {
+    if (!c) return set_error(SIFTMI_E_BADARG, "null ctx");
+    c->timing = enable != 0;
+    return SIFTMI_OK;
+}
+extern "C" int siftmi_reset_timings(siftmi_ctx *c) {
+    if (!c) return set_error(SIFTMI_E_BADARG, "null ctx");
+    (void)hipStreamSynchronize(c->stream);
+    t_collect(c);
+    memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_launches, 0, sizeof(c->t_launches));
+    return SIFTMI_OK;
+}
+extern "C" int siftmi_get_timings(siftmi_ctx *c, double *ms, int64_t *launches) {
+    if (!c) return set_error(SIFTMI_E_BADARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    t_collect(c);
+    for (int i = 0; i < SIFTMI_T_COUNT; i++) { if (ms) ms[i] = c->t_ms[i]; if (launches) launches[i] = c->t_launches[i]; }
+    return SIFTMI_OK;
+}
+extern "C" int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *c, int o) {
+    if (!c || o < 0 || o >= c->n_oct) return 0;
+    return 8ll * c->ow[o] * c->oh[o];
+}
+extern "C" int siftmi_time_blur(siftmi_ctx *c, int o, int layer, int iters, double *ms_per_launch) {
+    if (!c || !ms_per_launch || o < 0 || o >= c->n_oct || layer < 1 || layer > c->nspo + 2 || iters < 1)
+        return set_error(SIFTMI_E_BADARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    SeedSource none; memset(&none, 0, sizeof(none));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, c->stream));
+    for (int i = 0; i < iters; i++)
+        HIP_TRY((launch_blur<false>(c, c->stream, (c->taps[layer - 1] - 1) / 2, gauss_ptr(c, o, layer - 1), gauss_ptr(c, o, layer), c->ow[o],
+                                    c->oh[o], c->B, c->layer_w[layer - 1], none)));
+    HIP_TRY(hipEventRecord(b, c->stream));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = (double)ms / iters;
+    return SIFTMI_OK;
+}
+extern "C" int siftmi_synchronize(siftmi_ctx *c) {
+    if (!c) return set_error(SIFTMI_E_BADARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    t_collect(c);
+    return SIFTMI_OK;
+}

@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/siftmi.h declares; record layouts match the reference's C structs; no compute without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from siftmetal_amd import _capi
+    return _capi.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "siftmi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(siftmi_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from siftmetal_amd import _capi
+    assert declared == set(_capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_record_layouts_match_reference_structs():
+    from siftmetal_amd import _capi
+    # Sources/MetalShaders/include: SIFTExtremaResult 12 B, SIFTOrientationResult 152 B,
+    # SIFTDescriptorResult 524 B; SIFTKeypoint flattened = 44 B
+    assert _capi.extremum_dtype.itemsize == 12
+    assert _capi.keypoint_dtype.itemsize == 44
+    assert _capi.orientation_dtype.itemsize == 152
+    assert _capi.descriptor_reference_dtype.itemsize == 524
+    assert _capi.descriptor_dtype.itemsize == 136
+    assert C.sizeof(_capi.Config) == 4 * 29
+
+
+def test_defaults_are_the_reference_literals(lib):
+    from siftmetal_amd import _capi
+    cfg = _capi.default_config(512, 340)
+    assert (cfg.n_octaves, cfg.nspo, cfg.max_iterations, cfg.image_border) == (7, 3, 5, 5)
+    assert abs(cfg.dog_threshold - 0.0133) < 1e-9 and cfg.edge_threshold == 10.0 and abs(cfg.max_offset - 0.6) < 1e-7
+    assert cfg.lambda_orientation == 1.5 and abs(cfg.orientation_threshold - 0.8) < 1e-7 and cfg.orientation_smoothing == 6
+    assert abs(cfg.sigma_min - 0.8) < 1e-7 and cfg.delta_min == 0.5 and cfg.sigma_in == 0.5
+    assert cfg.descriptor_scales_per_octave == 3 and cfg.full_neighbourhood == 0 and cfg.max_batch == 1
+
+
+def test_descriptor_record_conversion(lib):
+    from siftmetal_amd import _capi
+    rng = np.random.default_rng(0)
+    d = np.zeros(5, _capi.descriptor_dtype)
+    d["keypoint"] = np.arange(5); d["theta"] = rng.uniform(0, 6, 5)
+    d["features"] = rng.integers(0, 256, (5, 128))
+    out = np.zeros(5, _capi.descriptor_reference_dtype)
+    lib.siftmi_descriptor_to_reference(d.ctypes.data, 5, out.ctypes.data)
+    assert (out["valid"] == 1).all() and np.array_equal(out["keypoint"], d["keypoint"])
+    assert np.array_equal(out["features"], d["features"].astype(np.int32)) and np.array_equal(out["theta"], d["theta"])
+
+
+def test_no_gpu_means_loud_failure(lib):
+    """The product path has no CPU fallback: without a HIP device create() fails with E_NODEVICE."""
+    import siftmetal_amd
+    from siftmetal_amd import _capi
+    if lib.siftmi_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(siftmetal_amd.SiftmiError) as e:
+        siftmetal_amd.Engine(64, 64)
+    assert e.value.code == _capi.E_NODEVICE
+    with pytest.raises(siftmetal_amd.SiftmiError):
+        siftmetal_amd.SIFT(0, siftmetal_amd.SIFT.Configuration(siftmetal_amd.IntegralSize(64, 64)))
+
+
+def test_product_package_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "siftmetal_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "sift_oracle" not in txt, f

@@ -1,0 +1,251 @@
+"""Parity of the hand-written HIP path (through the C ABI, libsiftmi.so) against the CPU oracle and
+the reference's golden fixtures.  Runs on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+
+from tests import parity
+from tests.synth import blob_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    import siftmetal_amd
+    return siftmetal_amd
+
+
+def _oracle(w, h, no, **kw):
+    from oracle import pyoracle
+    return pyoracle.Oracle(w, h, n_octaves=no, **kw)
+
+
+def _split(arr, counts):
+    out, pos = [], 0
+    for c in counts:
+        out.append(arr[pos:pos + c])
+        pos += c
+    return out
+
+
+CASES = [
+    ("butterfly", None, 7),                 # the reference's own test image, its default 7 octaves
+    ("blob640", (640, 480), 3),             # BASELINE configs[0]
+    ("odd", (157, 93), 3),                  # widths not multiples of 4 -> scalar load/store path
+    ("tiny", (40, 36), 2),
+]
+
+
+def _image(name, size, butterfly_bgra):
+    if name == "butterfly":
+        return butterfly_bgra
+    if name == "odd":
+        return blob_frame(size[0], size[1], 7, n_blobs=60, gray=True)
+    return blob_frame(size[0], size[1], 1)
+
+
+@pytest.mark.parametrize("name,size,no", CASES)
+def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no):
+    img = _image(name, size, butterfly_bgra)
+    h, w = img.shape[:2]
+    eng = sm.Engine(w, h, n_octaves=no, keep_descriptor_floats=1)
+    orc = _oracle(w, h, no)
+    ref = orc.run(img, want_float=True)
+
+    kps, kc, ds, dc = eng.detect_describe_batch(img[None])
+    st = eng.stats()
+    g_kp, g_ds = _split(kps, kc[0]), _split(ds, dc[0])
+
+    # schedule
+    for o in range(no):
+        assert eng.octave_size(o)[:2] == orc.octave_size(o) and eng.octave_size(o)[2] == orc.delta(o)
+        for s in range(6):
+            assert eng.sigma(o, s) == orc.sigma(o, s)
+    for l in range(6):
+        assert np.array_equal(eng.weights(l), orc.weights(l))
+
+    tot_kp = tot_match = 0
+    for o in range(no):
+        # 1. Gaussian stack: bit-exact
+        for s in range(6):
+            G, R = eng.gaussian(o, s), orc.gaussian(o, s)
+            assert np.array_equal(G, R), "octave %d layer %d: max |d| = %g" % (o, s, np.abs(G - R).max())
+        # 2. extrema: identical raw count, identical candidate set
+        assert st["raw_extrema"][0, o] == len(ref[o]["extrema"])
+        cand = parity.prefilter_extrema(orc, o, ref[o]["extrema"])
+        assert parity.ext_set(eng.extrema(o)) == parity.ext_set(cand)
+        assert st["candidates"][0, o] == len(cand)
+        # 3. keypoints
+        rep, pairs = parity.compare_keypoints(g_kp[o], ref[o]["keypoints"])
+        tot_kp += max(rep["n_gpu"], rep["n_ref"]); tot_match += rep["matched"]
+        if pairs:
+            assert rep["max_abs_px"] <= parity.TOL_ABS_PX and rep["max_subscale"] <= parity.TOL_SUBSCALE
+            assert rep["max_value"] <= parity.TOL_VALUE and rep["max_sigma_rel"] <= parity.TOL_SIGMA_REL
+            assert rep["max_norm"] == 0.0
+        assert (g_kp[o]["octave"] == o).all()
+        # sorted by (scale, y, x)
+        key = g_kp[o]["scale"].astype(np.int64) * (1 << 40) + g_kp[o]["y"].astype(np.int64) * (1 << 20) + g_kp[o]["x"]
+        assert (np.diff(key) >= 0).all()
+        # 4./5. orientation + descriptors from IDENTICAL keypoints (the GPU's), so that float noise
+        # in refinement does not leak into the comparison of these stages
+        okp = parity.to_oracle_keypoints(g_kp[o])
+        r_ori = orc.orientations(o, okp)
+        r_desc, r_f32 = orc.descriptors(o, okp, r_ori, want_float=True)
+        g_ori = eng.orientations(o)
+        orep = parity.compare_orientations(g_ori, r_ori, len(okp))
+        assert orep["count_mismatch"] <= max(1, len(okp) // 200), orep
+        assert orep["max_dtheta"] <= parity.TOL_THETA, orep
+        assert st["oriented"][0, o] == int((g_ori["count"] >= 0).sum())
+        drep = parity.compare_descriptors(g_ds[o], eng.descriptor_floats(o), r_desc, r_f32, r_ori)
+        assert drep["unmatched"] <= 2 * max(1, len(okp) // 200), drep
+        assert drep["max_bin_diff"] <= parity.MAX_DESC_BIN_DIFF, drep
+        assert drep["frac_differing"] <= parity.MAX_DESC_BIN_FRAC, drep
+        assert drep["max_l2_float"] <= parity.TOL_DESC_L2, drep
+    assert tot_match >= 0.995 * tot_kp - 1, (tot_match, tot_kp)
+
+
+def test_butterfly_against_ipol_fixtures(sm, butterfly_bgra, ipol):
+    """The reference's own golden data, checked directly on the HIP output."""
+    eng = sm.Engine(512, 340, n_octaves=7)
+    kps, counts = eng.detect(butterfly_bgra)
+    assert counts.tolist() == [723, 419, 127, 28, 8, 4, 0]
+    for o in range(4):
+        for s in range(6):
+            png = ipol["scalespace_o%d_s%d" % (o, s)].astype(np.float32)
+            assert np.abs(255.0 * eng.gaussian(o, s) - png).max() <= 1.5
+    k5 = kps[kps["octave"] < 5]
+    ours = np.stack([k5["abs_y"], k5["abs_x"]], 1).astype(np.float64)
+    gold = ipol["on_edge"][:, :2].astype(np.float64)
+    d = np.sqrt(((ours[:, None] - gold[None]) ** 2).sum(-1))
+    assert (d.min(1) < 0.01).mean() >= 0.98
+    assert (d.min(0) < 0.5).mean() >= 0.985
+    # exact raw-extrema known answer with the 26-neighbour switch (extra_NES_butterfly.txt: 3068 rows)
+    eng26 = sm.Engine(512, 340, n_octaves=5, full_neighbourhood=1)
+    eng26.detect(butterfly_bgra)
+    assert eng26.stats()["raw_extrema"][0].tolist() == [1880, 904, 224, 52, 8]
+
+
+def test_api_getKeypoints_getDescriptors_roundtrip(sm, butterfly_bgra):
+    """SIFT.getKeypoints / getDescriptors (SIFT.swift:147, :207) through the object API, incl. a
+    caller-filtered keypoint list; must equal the fused batch path."""
+    sift = sm.SIFT(device=0, configuration=sm.SIFT.Configuration(inputSize=sm.IntegralSize(512, 340)))
+    kpo = sift.getKeypoints(butterfly_bgra)
+    assert [len(k) for k in kpo] == [723, 419, 127, 28, 8, 4, 0]
+    desc = sift.getDescriptors(kpo)
+    assert [len(d) for d in desc] == [802, 466, 125, 23, 4, 0, 0]
+    d0 = desc[0][0]
+    assert len(d0.features) == 128 and 0 <= min(d0.features) and max(d0.features) <= 255
+    assert abs(d0.rawFeatures[3] - d0.features[3] / 255.0) < 1e-6 and 0 <= d0.theta < 2 * np.pi
+    eng = sm.Engine(512, 340, n_octaves=7)
+    kps, kc, ds, dc = eng.detect_describe_batch(butterfly_bgra[None])
+    assert dc[0].tolist() == [len(d) for d in desc]
+    f_api = np.array([d.features for dd in desc for d in dd], np.uint8)
+    assert np.array_equal(f_api, ds["features"])
+    # filtered list: every other keypoint of octave 0
+    sub = [kpo[0][::2]] + [[] for _ in range(6)]
+    dsub = sift.getDescriptors(sub)
+    want = [d for d in desc[0] if kpo[0].index(d.keypoint) % 2 == 0]
+    assert len(dsub[0]) == len(want)
+    assert all(a.features == b.features and a.keypoint is b.keypoint for a, b in zip(dsub[0], want))
+    with pytest.raises(ValueError):
+        sift.getDescriptors(kpo[:3])
+
+
+def test_batch_equals_single_and_is_deterministic(sm):
+    """Lock-step batching (max_batch 3, 5 frames -> sub-batches 3+2) returns per frame exactly what a
+    single-frame context returns; two runs are bit-identical."""
+    frames = np.stack([blob_frame(320, 240, i) for i in range(5)])
+    eb = sm.Engine(320, 240, n_octaves=3, max_batch=3)
+    a = eb.detect_describe_batch(frames)
+    b = eb.detect_describe_batch(frames)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    e1 = sm.Engine(320, 240, n_octaves=3, max_batch=1)
+    kpos = dpos = 0
+    for f in range(5):
+        k1, kc1, d1, dc1 = e1.detect_describe_batch(frames[f:f + 1])
+        assert np.array_equal(kc1[0], a[1][f]) and np.array_equal(dc1[0], a[3][f])
+        nk, nd = int(kc1.sum()), int(dc1.sum())
+        assert np.array_equal(k1, a[0][kpos:kpos + nk]) and np.array_equal(d1, a[2][dpos:dpos + nd])
+        kpos += nk; dpos += nd
+    assert kpos == len(a[0]) and dpos == len(a[2]) and dpos > 100
+
+
+def test_formats_agree(sm):
+    g = blob_frame(200, 160, 4, gray=True)
+    bgra = np.ascontiguousarray(np.repeat(g[..., None], 4, 2))
+    eng = sm.Engine(200, 160, n_octaves=3)
+    r8 = eng.detect_describe_batch(g[None])
+    G8 = eng.gaussian(0, 3)
+    rf = eng.detect_describe_batch((g.astype(np.float32) / np.float32(255))[None])
+    assert np.array_equal(G8, eng.gaussian(0, 3))
+    for x, y in zip(r8, rf):
+        assert np.array_equal(x, y)
+    rb = eng.detect_describe_batch(bgra[None])
+    assert np.abs(eng.gaussian(0, 3) - G8).max() < 3e-7          # luma weights sum to 1 within f32 rounding
+    assert abs(len(rb[0]) - len(r8[0])) <= 2
+
+
+def test_errors_and_capacity(sm):
+    from siftmetal_amd import _capi
+    with pytest.raises(sm.SiftmiError) as e:
+        sm.Engine(64, 64, n_octaves=40)
+    assert e.value.code == _capi.E_BADARG
+    with pytest.raises(sm.SiftmiError) as e:
+        sm.Engine(16, 16, n_octaves=7)                      # octave 6 would be empty
+    assert e.value.code == _capi.E_BADARG
+    with pytest.raises(sm.SiftmiError) as e:
+        sm.Engine(64, 64, nspo=9)
+    assert e.value.code == _capi.E_BADARG
+    with pytest.raises(sm.SiftmiError) as e:
+        sm.Engine(64, 64, device=99)
+    assert e.value.code == _capi.E_BADARG
+    img = blob_frame(320, 240, 0)
+    eng = sm.Engine(320, 240, n_octaves=3, max_keypoints=16, max_descriptors=16)
+    with pytest.raises(sm.SiftmiError) as e:
+        eng.detect_describe_batch(img[None])
+    assert e.value.code == _capi.E_CAPACITY and "keypoints" in str(e.value)
+    kps, kc, ds, dc = eng.detect_describe_batch(img[None], allow_capacity=True)     # truncated, never UB
+    assert kc.max() <= 16 and dc.max() <= 16
+    fresh = sm.Engine(320, 240, n_octaves=3)
+    with pytest.raises(sm.SiftmiError) as e:
+        fresh.describe(np.zeros(0, sm.keypoint_dtype), np.zeros(3, np.int32))
+    assert e.value.code == _capi.E_STATE
+    # empty / flat image: no keypoints, no crash
+    flat = np.full((240, 320), 128, np.uint8)
+    k, kc, d, dc = fresh.detect_describe_batch(flat[None])
+    assert len(k) == 0 and len(d) == 0 and kc.sum() == 0
+
+
+def test_full_size_1080p_properties(sm):
+    """BASELINE configs[1] size (1920x1080, 4 octaves): size-independent properties + a sampled
+    oracle comparison (oracle on the full frame takes a few seconds on 8 cores)."""
+    img = blob_frame(1920, 1080, 0)
+    eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=2)
+    frames = np.stack([img, img])
+    k, kc, d, dc = eng.detect_describe_batch(frames)
+    # the same frame twice in one lock-step batch -> identical halves
+    assert np.array_equal(kc[0], kc[1]) and np.array_equal(dc[0], dc[1])
+    nk, nd = int(kc[0].sum()), int(dc[0].sum())
+    assert np.array_equal(k[:nk], k[nk:]) and np.array_equal(d[:nd], d[nd:])
+    assert nk > 1000 and nd >= nk * 0.9
+    # blur of a constant image is that constant (weights sum to 1): idempotence of the pyramid on flats
+    flat = np.full((1080, 1920), 77, np.uint8)
+    eng.detect_describe_batch(np.stack([flat, flat]))
+    for o in range(4):
+        assert np.abs(eng.gaussian(o, 5) - np.float32(77 / 255.0)).max() < 2e-6
+    # oracle comparison at full size
+    orc = _oracle(1920, 1080, 4)
+    ref = orc.run(img)
+    eng.detect_describe_batch(frames)
+    for o in range(4):
+        assert np.array_equal(eng.gaussian(o, 5, frame=1), orc.gaussian(o, 5))
+        assert eng.stats()["raw_extrema"][1, o] == len(ref[o]["extrema"])
+    got = _split(k[:nk], kc[0])
+    tot = match = 0
+    for o in range(4):
+        rep, _ = parity.compare_keypoints(got[o], ref[o]["keypoints"])
+        tot += max(rep["n_gpu"], rep["n_ref"]); match += rep["matched"]
+        assert rep["max_abs_px"] <= parity.TOL_ABS_PX
+    assert match >= 0.995 * tot
+    assert abs(nd - sum(len(r["descriptors"]) for r in ref)) <= max(3, nd // 200)
