@@ -141,3 +141,15 @@ def to_oracle_keypoints(g):
                  ("absY", "abs_y"), ("normX", "norm_x"), ("normY", "norm_y"), ("sigma", "sigma"), ("value", "value")]:
         out[a] = g[b]
     return out
+
+
+def to_oracle_orientations(g_ori):
+    """siftmi_orientation records (count -1 = rejected by the border filter) -> the oracle's list of
+    accepted keypoints, so that the descriptor stage can be compared on bit-identical (keypoint, theta)."""
+    from oracle import pyoracle
+    keep = g_ori["count"] >= 0
+    out = np.zeros(int(keep.sum()), pyoracle.orientation_dtype)
+    out["keypoint"] = g_ori["keypoint"][keep]
+    out["count"] = g_ori["count"][keep]
+    out["orientations"] = g_ori["orientations"][keep]
+    return out

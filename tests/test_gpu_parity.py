@@ -90,13 +90,16 @@ def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no):
         # in refinement does not leak into the comparison of these stages
         okp = parity.to_oracle_keypoints(g_kp[o])
         r_ori = orc.orientations(o, okp)
-        r_desc, r_f32 = orc.descriptors(o, okp, r_ori, want_float=True)
         g_ori = eng.orientations(o)
         orep = parity.compare_orientations(g_ori, r_ori, len(okp))
         assert orep["count_mismatch"] <= max(1, len(okp) // 200), orep
         assert orep["max_dtheta"] <= parity.TOL_THETA, orep
         assert st["oriented"][0, o] == int((g_ori["count"] >= 0).sum())
-        drep = parity.compare_descriptors(g_ds[o], eng.descriptor_floats(o), r_desc, r_f32, r_ori)
+        # ... and the descriptor stage from the GPU's own (keypoint, theta) list, bit-identical inputs
+        in_ori = parity.to_oracle_orientations(g_ori)
+        r_desc, r_f32 = orc.descriptors(o, okp, in_ori, want_float=True)
+        drep = parity.compare_descriptors(g_ds[o], eng.descriptor_floats(o), r_desc, r_f32, in_ori)
+        assert drep["max_dtheta"] == 0.0 and drep["n_gpu"] == drep["n_ref"], drep
         assert drep["unmatched"] <= 2 * max(1, len(okp) // 200), drep
         assert drep["max_bin_diff"] <= parity.MAX_DESC_BIN_DIFF, drep
         assert drep["frac_differing"] <= parity.MAX_DESC_BIN_FRAC, drep
@@ -144,7 +147,8 @@ def test_api_getKeypoints_getDescriptors_roundtrip(sm, butterfly_bgra):
     # filtered list: every other keypoint of octave 0
     sub = [kpo[0][::2]] + [[] for _ in range(6)]
     dsub = sift.getDescriptors(sub)
-    want = [d for d in desc[0] if kpo[0].index(d.keypoint) % 2 == 0]
+    pos_of = {id(k): i for i, k in enumerate(kpo[0])}          # identity, not ==: duplicates exist (App. A #11)
+    want = [d for d in desc[0] if pos_of[id(d.keypoint)] % 2 == 0]
     assert len(dsub[0]) == len(want)
     assert all(a.features == b.features and a.keypoint is b.keypoint for a, b in zip(dsub[0], want))
     with pytest.raises(ValueError):
