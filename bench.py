@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- SIFT detect+describe throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path (gray -> 2x bilinear -> Gaussian pyramid -> DoG extrema ->
+refinement -> orientation -> 128-D descriptors, packed results) over a batch of synthetic
+1920x1080 frames per GPU (BASELINE.json configs[2]/[3]: 64 frames per GPU, 4 octaves x 3 scales per
+octave), frames already resident in HBM, results left in HBM; with N > 1 every rank processes its own
+64 frames (frame-per-GPU sharding, weak scaling) and the step ends with the RCCL all-gather of the
+descriptor buffers.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     Gaussian-layer blur kernel (the "pyramid kernel"): algorithmic bytes (8 B per octave
+               pixel per layer) / average launch duration measured with hipEvents on the
+               launch stream in a second, identical, event-instrumented pass of K steps.
+  cpu_baseline the CPU oracle (a port of the reference's algorithm; kind "port") timed on the host
+               cores on a bounded sample of the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+W, H, N_OCT, NSPO = 1920, 1080, 4, 3
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_frames(n, distinct):
+    from tests.synth import blob_frame
+    base = [blob_frame(W, H, i) for i in range(min(n, distinct))]
+    return np.stack([base[i % len(base)] for i in range(n)])
+
+
+def cpu_baseline(frames, seconds_budget=20.0):
+    """Times the oracle (oracle/sift_oracle.c, OpenMP) on a bounded sample of the same frames."""
+    from oracle import pyoracle
+    orc = pyoracle.Oracle(W, H, n_octaves=N_OCT, nspo=NSPO)
+    t0 = time.time()
+    done = 0
+    n_desc = 0
+    while done < len(frames) and (done == 0 or (time.time() - t0) * (done + 1) / done < seconds_budget):
+        tot, _ = orc.detect_describe_counts(frames[done])
+        n_desc += tot
+        done += 1
+    dt = time.time() - t0
+    return {"value": round(done * W * H / dt / 1e6, 4), "unit": "Mpixels/s", "cores": pyoracle.num_threads(), "kind": "port",
+            "sample": "%d x %dx%d synthetic frames (same generator), %d octaves, %.1f s, %d descriptors" % (done, W, H, N_OCT, dt, n_desc)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "8")), help="frames processed in lock-step per launch")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (cycled to fill the batch)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    ge.build()
+    import siftmetal_amd as sm
+    from siftmetal_amd import stream as smstream
+
+    F = args.frames
+    frames_np = make_frames(F, args.distinct)
+    # every rank gets different frames (rotate) so the gathered descriptors are not copies
+    frames_np = np.roll(frames_np, rank, axis=0)
+    d_frames = torch.from_numpy(frames_np).to(dev)
+    eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F))
+    runner = smstream.FrameStream(eng, F, device=dev, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        runner.run(d_frames)
+        if world > 1:
+            runner.all_gather()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * F * W * H * args.steps / dt / 1e6
+
+    res = runner.results_host()
+    log("rank0 per-step: %d keypoints, %d descriptors over %d frames; %.3f ms/step, %.3f ms/frame" %
+        (res["n_keypoints"], res["n_descriptors"], F, ms_per_step, ms_per_step / F))
+
+    out = {"metric": "Mpixels/sec detect+describe (1920x1080, 4 octaves)", "value": round(value, 2), "unit": "Mpixels/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%d x 1920x1080 BGRA8 frames per GPU per step (BASELINE configs[2]/[3]), %d octaves x %d scales/octave, "
+                                  "detect+describe, frames and results resident in HBM%s" %
+                                  (F, N_OCT, NSPO, ", RCCL all-gather of descriptors" if world > 1 else ""),
+                      "frames_per_gpu": F, "lockstep_batch": eng.max_batch, "parallelism": "frame-per-GPU x%d" % world,
+                      "keypoints_per_step_rank0": res["n_keypoints"], "descriptors_per_step_rank0": res["n_descriptors"]}}
+
+    if rank == 0 and not args.no_roofline:
+        # second, identical pass with per-launch hipEvents on the launch stream
+        eng.enable_timings(True)
+        eng.reset_timings()
+        for _ in range(args.steps):
+            runner.run(d_frames)
+        torch.cuda.synchronize()
+        tm = eng.timings()
+        eng.enable_timings(False)
+        blur_ms, blur_n = tm["blur"]
+        # one blur launch of octave o moves 8 B x N_o x (frames in the launch); per step every octave
+        # gets nspo+2 launches per sub-batch
+        bytes_per_step = sum(eng.blur_algorithmic_bytes(o) for o in range(N_OCT)) * (NSPO + 2) * F
+        total_bytes = bytes_per_step * args.steps
+        achieved = total_bytes / (blur_ms * 1e-3) / 1e9 if blur_ms > 0 else 0.0
+        stage_ms = {k: round(v[0] / args.steps, 4) for k, v in tm.items()}
+        log("stage ms/step:", stage_ms)
+        per_layer = {}
+        for layer in range(1, NSPO + 3):
+            ms = eng.time_blur(0, layer, 10)
+            per_layer["o0_l%d_taps%d" % (layer, len(eng.weights(layer)))] = round(eng.blur_algorithmic_bytes(0) * eng.max_batch / (ms * 1e-3) / 1e9, 1)
+        log("octave-0 blur GB/s by layer:", per_layer)
+        out["roofline"] = {"bound": "hbm", "kernel": "blur_layer_kernel<R> (Gaussian layer, fused X+Y)", "achieved": round(achieved, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "launches": blur_n, "avg_launch_ms": round(blur_ms / max(blur_n, 1), 5),
+                           "algorithmic_bytes_per_launch_avg": int(total_bytes / max(blur_n, 1)),
+                           "octave0_GBps_by_layer": per_layer, "stage_ms_per_step": stage_ms,
+                           "measured_in": "second identical pass of K steps, hipEvents around every launch on the launch stream"}
+    if rank == 0 and not args.no_cpu and world == 1:
+        out["cpu_baseline"] = cpu_baseline(frames_np)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+"""Batched frame stream on one GPU: frames and results stay in HBM (torch tensors own the memory,
+the HIP path runs on torch's current stream), optional RCCL all-gather of the packed results."""
+import numpy as np
+import torch
+
+from . import _capi, dist as smdist
+
+
+class FrameStream:
+    def __init__(self, engine, frames_per_step, device, world_size=1, kp_per_frame=32768, desc_per_frame=49152):
+        self.eng = engine
+        self.F = frames_per_step
+        self.device = device
+        self.world = world_size
+        self.kp_cap = kp_per_frame * frames_per_step
+        self.desc_cap = desc_per_frame * frames_per_step
+        self.kp = torch.empty(self.kp_cap * smdist.KP_BYTES, dtype=torch.uint8, device=device)
+        self.desc = torch.empty(self.desc_cap * smdist.DESC_BYTES, dtype=torch.uint8, device=device)
+        self.counts = torch.zeros((2, frames_per_step, engine.n_octaves), dtype=torch.int32, device=device)
+        self.totals = torch.zeros(2, dtype=torch.int32, device=device)
+        self.gathered = None
+
+    def run(self, d_frames):
+        """d_frames: uint8 [F, H, W, 4] (BGRA) / [F, H, W] (gray) or float32 [F, H, W] device tensor."""
+        assert d_frames.is_cuda and d_frames.shape[0] == self.F and d_frames.is_contiguous()
+        if d_frames.dtype == torch.uint8 and d_frames.dim() == 4:
+            fmt = _capi.FMT_BGRA8
+        elif d_frames.dtype == torch.uint8:
+            fmt = _capi.FMT_GRAY8
+        else:
+            fmt = _capi.FMT_GRAYF32
+        es = d_frames.element_size()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.eng.detect_describe_batch_device(self.F, d_frames.data_ptr(), fmt, d_frames.stride(1) * es, d_frames.stride(0) * es,
+                                              self.kp.data_ptr(), self.kp_cap, self.desc.data_ptr(), self.desc_cap,
+                                              self.counts.data_ptr(), self.totals.data_ptr(), stream)
+
+    def all_gather(self):
+        self.gathered = smdist.gather_results(self.kp, self.desc, self.counts, self.totals)
+        return self.gathered
+
+    def results_host(self):
+        tot = self.totals.cpu().numpy()
+        nk, nd = int(tot[0]), int(tot[1])
+        kp = self.kp[:nk * smdist.KP_BYTES].cpu().numpy().view(_capi.keypoint_dtype)
+        ds = self.desc[:nd * smdist.DESC_BYTES].cpu().numpy().view(_capi.descriptor_dtype)
+        return {"n_keypoints": nk, "n_descriptors": nd, "keypoints": kp, "descriptors": ds, "counts": self.counts.cpu().numpy()}

@@ -1,0 +1,103 @@
+"""world_size-2 gloo test (CPU) of the N>1 path: frame sharding + count exchange + padded all-gather
+of packed keypoint/descriptor buffers (siftmetal_amd/dist.py).  The per-rank buffers are produced by
+the CPU oracle here (checker role) because the product path needs a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_results(rank, world, n_frames):
+    """Packed siftmi-format records for this rank's frames, computed with the oracle."""
+    from oracle import pyoracle
+    from siftmetal_amd import _capi, dist as smdist
+    from tests.synth import blob_frame
+    mine = smdist.shard_frames(n_frames, world, rank)
+    kps, descs = [], []
+    counts = np.zeros((2, (n_frames + world - 1) // world, 2), np.int32)   # equal shape on every rank
+    for fi, f in enumerate(mine):
+        img = blob_frame(96, 80, f, n_blobs=30 + 10 * f)
+        res = pyoracle.Oracle(96, 80, n_octaves=2).run(img)
+        for o, r in enumerate(res):
+            k = np.zeros(len(r["keypoints"]), _capi.keypoint_dtype)
+            for a, b in [("octave", "octave"), ("scale", "scale"), ("sub_scale", "subScale"), ("x", "x"), ("y", "y"), ("abs_x", "absX"),
+                         ("abs_y", "absY"), ("norm_x", "normX"), ("norm_y", "normY"), ("sigma", "sigma"), ("value", "value")]:
+                k[a] = r["keypoints"][b]
+            d = np.zeros(len(r["descriptors"]), _capi.descriptor_dtype)
+            d["keypoint"] = r["orientations"]["keypoint"][r["descriptors"]["keypoint"]] if len(d) else 0
+            d["theta"] = r["descriptors"]["theta"]
+            d["features"] = r["descriptors"]["features"].astype(np.uint8)
+            kps.append(k); descs.append(d)
+            counts[0, fi, o], counts[1, fi, o] = len(k), len(d)
+    return mine, np.concatenate(kps), np.concatenate(descs), counts
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from siftmetal_amd import _capi, dist as smdist
+        mine, kp, ds, counts = _rank_results(rank, world, n_frames)
+        cap_kp, cap_ds = 4096, 4096
+        kp_b = torch.zeros(cap_kp * smdist.KP_BYTES, dtype=torch.uint8)
+        ds_b = torch.zeros(cap_ds * smdist.DESC_BYTES, dtype=torch.uint8)
+        kp_b[:kp.nbytes] = torch.from_numpy(kp.view(np.uint8).copy())
+        ds_b[:ds.nbytes] = torch.from_numpy(ds.view(np.uint8).copy())
+        totals = torch.tensor([len(kp), len(ds)], dtype=torch.int32)
+        g = smdist.gather_results(kp_b, ds_b, torch.from_numpy(counts), totals)
+        out = {"rank": rank, "totals": g["totals"].numpy().copy(), "counts": g["counts"].numpy().copy()}
+        rows = []
+        for r in range(world):
+            nk, nd = int(g["totals"][r, 0]), int(g["totals"][r, 1])
+            rows.append((g["keypoints"][r, :nk * 44].numpy().tobytes(), g["descriptors"][r, :nd * 136].numpy().tobytes()))
+        out["rows"] = rows
+        out["own"] = (kp.tobytes(), ds.tobytes(), mine)
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_frames():
+    from siftmetal_amd import dist as smdist
+    assert smdist.shard_frames(5, 2, 0) == [0, 2, 4] and smdist.shard_frames(5, 2, 1) == [1, 3]
+    got = sorted(sum((smdist.shard_frames(512, 8, r) for r in range(8)), []))
+    assert got == list(range(512)) and all(len(smdist.shard_frames(512, 8, r)) == 64 for r in range(8))
+    assert smdist.shard_frames(3, 8, 5) == []
+
+
+@pytest.mark.timeout(300)
+def test_gather_results_world2_gloo():
+    world, n_frames = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    outs.sort(key=lambda o: o["rank"])
+    # every rank sees every rank's exact bytes, ragged sizes included
+    assert np.array_equal(outs[0]["totals"], outs[1]["totals"])
+    assert (outs[0]["totals"][0] != outs[0]["totals"][1]).any()        # ragged on purpose (3 vs 2 frames)
+    for viewer in outs:
+        for r in range(world):
+            assert viewer["rows"][r][0] == outs[r]["own"][0] and viewer["rows"][r][1] == outs[r]["own"][1]
+    assert outs[0]["own"][2] == [0, 2, 4] and outs[1]["own"][2] == [1, 3]
+    tot = outs[0]["totals"]
+    assert tot[:, 1].min() > 10
