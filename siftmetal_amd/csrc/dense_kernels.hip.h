@@ -25,6 +25,9 @@
 
 namespace siftmi {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) volatile f32x4 lds_cv_f32x4;      // LDS-qualified, see blur phase 1
+
 struct TapWeights { float w[32]; };            // ConvolutionParameters.weights (ConvolutionSeries.h:13-21)
 
 enum { FMT_BGRA8 = 0, FMT_GRAY8 = 1, FMT_GRAYF32 = 2 };
@@ -83,93 +86,157 @@ __device__ __forceinline__ float seed_sample(const unsigned char *frame, const S
     return fx * (fy * c0 + (1.0f - fy) * c1) + (1.0f - fx) * (fy * c2 + (1.0f - fy) * c3);
 }
 
-template <int R>
-struct BlurGeom {
-    static constexpr int RP = (R + 3) & ~3;       // halo rounded up so LDS rows stay 16-B aligned
-    static constexpr int TW = 128;                // tile width  (outputs)
-    static constexpr int TH = 32;                 // tile height (outputs)
-    static constexpr int RB = TH / 8;             // output rows per lane in the vertical pass
-    static constexpr int LW = TW + 2 * RP;        // LDS row pitch (floats)
-    static constexpr int LH = TH + 2 * R;         // LDS rows
-    static constexpr int NT = 2 * R + 1;          // taps
-    static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
+// Tap weights live in VGPRs.  Measured on MI355X (tools/ubench/ubench_valu.hip): v_fmac_f32 with an
+// SGPR multiplicand issues at HALF the rate of the all-VGPR form (57-67 vs 108-126 TFLOP/s), so
+// the kernarg weights are copied into vector registers once per wave; the asm keeps the compiler
+// from folding the copy back into an SGPR operand.
+template <int NT>
+struct VTaps {
+    float w[NT];
+    __device__ __forceinline__ explicit VTaps(const TapWeights &wt) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) asm volatile("v_mov_b32 %0, %1" : "=v"(w[i]) : "s"(wt.w[i]));
+    }
 };
 
-// One Gaussian layer: dst = blur_R(src), separable, mirror extension, one frame per blockIdx.z.
-// SEED = true: src is ignored and the input is seed_sample() of the frame's pixels.
-template <int R, bool SEED>
-__global__ __launch_bounds__(256) void blur_layer_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                        int w, int h, size_t src_frame_stride, size_t dst_frame_stride,
-                                                        TapWeights wt, SeedSource seed) {
-    using G = BlurGeom<R>;
+// ------------------------------------------------------------------------------------------------
+// One Gaussian layer: dst = blur_R(src), separable, mirror extension.  SEED = true: src is ignored and
+// the input is seed_sample() of the frame's pixels.  Tile height, workgroup size, vertical register
+// blocking, occupancy hint and the XCD-aware tile order are template parameters so that
+// tools/ubench/blur_variants.hip can time variants; BlurShip below is the shipping choice.
+template <int R, int TH_, int NTHR_, int HO_, int RB_>
+struct Blur2Geom {
+    static constexpr int RP = (R + 3) & ~3;
+    static constexpr int TW = 128, TH = TH_, NTHR = NTHR_, HO = HO_, RB = RB_;
+    static constexpr int LW = TW + 2 * RP, LH = TH + 2 * R, NT = 2 * R + 1;
+    static constexpr int V_ITEMS = (TW / 4) * (TH / RB);
+    static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
+    // seed variant: luma of the input pixels under the staged 2x window, computed once per workgroup
+    static constexpr int LWI = LW / 2 + 3, LHI = LH / 2 + 3;
+    static constexpr size_t seed_lds_bytes = lds_bytes + (size_t)LWI * LHI * sizeof(float);
+    static_assert(HO == 4, "horizontal pass computes 4 adjacent outputs per lane");
+    static_assert(TH % RB == 0, "TH must be a multiple of RB");
+};
+
+template <int R, int TH_, int NTHR_, int HO_, int RB_, bool SEED, int MINW = 1, int KCH = 0, bool XCD = false>
+__global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                           size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt, SeedSource seed, int n_frames) {
+    using G = Blur2Geom<R, TH_, NTHR_, HO_, RB_>;
+    constexpr int NTHR = G::NTHR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * G::TW, y0 = blockIdx.y * G::TH;
-    const int frame = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, frame = blockIdx.z;
+    if (XCD) {
+        // 1-D launch; workgroups are dealt round-robin over the 8 XCDs (b % 8 = XCD group), so give
+        // every XCD one contiguous run of tiles: neighbouring tiles then share an L2 and the halo
+        // rows/columns are L2 hits instead of a second fetch through the fabric.
+        const int tx = (w + G::TW - 1) / G::TW, ty = (h + G::TH - 1) / G::TH;
+        const int total = tx * ty * n_frames;
+        const int chunk = (total + 7) >> 3;
+        const int t = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        if (t >= total) return;
+        frame = t / (tx * ty);
+        const int r = t - frame * (tx * ty);
+        by = r / tx; bx = r - by * tx;
+    }
+    const int x0 = bx * G::TW, y0 = by * G::TH;
     const float *__restrict__ in = SEED ? nullptr : src + (size_t)frame * src_frame_stride;
     float *__restrict__ out = dst + (size_t)frame * dst_frame_stride;
     const unsigned char *px = SEED ? seed.pixels + (size_t)frame * seed.frame_stride : nullptr;
 
-    // ---- phase 0: stage the input window, mirror extension resolved here ---------------------
     const bool interior = (x0 - G::RP >= 0) && (x0 + G::TW + G::RP <= w) && (y0 - R >= 0) && (y0 + G::TH + R <= h);
     if (!SEED && interior && (w & 3) == 0) {
-        constexpr int V = G::LW / 4;                       // float4 per LDS row
-        for (int idx = tid; idx < G::LH * V; idx += 256) {
+        constexpr int V = G::LW / 4;
+        for (int idx = tid; idx < G::LH * V; idx += NTHR) {
             const int ly = idx / V, lv = idx - ly * V;
             const float4 v = *reinterpret_cast<const float4 *>(in + (size_t)(y0 - R + ly) * w + (x0 - G::RP) + 4 * lv);
             *reinterpret_cast<float4 *>(lds + ly * G::LW + 4 * lv) = v;
         }
-    } else {
-        for (int idx = tid; idx < G::LH * G::LW; idx += 256) {
+    } else if (SEED) {
+        // luma (ConvertSRGBToGrayscale.metal) of every input pixel the staged window can touch, once,
+        // into LDS; the 2x bilinear samples (BilinearUpScale.metal) are then formed from LDS.  Each
+        // luma is reused by >= 4 upscaled samples, and the byte->float divisions are the expensive part.
+        float *lum = lds + G::LH * G::LW;
+        const int ix0 = ((x0 - G::RP) >> 1) - 1, iy0 = ((y0 - R) >> 1) - 1;
+        for (int idx = tid; idx < G::LHI * G::LWI; idx += NTHR) {
+            const int ly = idx / G::LWI, lx = idx - ly * G::LWI;
+            lum[idx] = luma_at(px, seed, ix0 + lx, iy0 + ly);             // 0 outside the image
+        }
+        __syncthreads();
+        const int wi = seed.in_w, hi = seed.in_h;
+        const float dx = (float)wi / (float)w, dy = (float)hi / (float)h;
+        for (int idx = tid; idx < G::LH * G::LW; idx += NTHR) {
             const int ly = idx / G::LW, lx = idx - ly * G::LW;
             const int sx = symm(x0 - G::RP + lx, w), sy = symm(y0 - R + ly, h);
-            float v;
-            if (SEED) v = seed_sample(px, seed, sx, sy, w, h);
-            else v = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : in[(size_t)sy * w + sx];
+            float v = 0.0f;
+            if (sx >= 0 && sy >= 0 && sx < w && sy < h) {                 // BilinearUpScale.metal:24-61
+                const float x = (float)sx * dx, y = (float)sy * dy;
+                int im = (int)x, jm = (int)y;
+                int ip = im + 1, jp = jm + 1;
+                if (ip >= wi) ip = 2 * wi - 1 - ip;
+                if (im >= wi) im = 2 * wi - 1 - im;
+                if (jp >= hi) jp = 2 * hi - 1 - jp;
+                if (jm >= hi) jm = 2 * hi - 1 - jm;
+                const float fx = x - floorf(x), fy = y - floorf(y);
+                auto L = [&](int i, int j) -> float {
+                    const int a = i - ix0, b = j - iy0;
+                    if (a >= 0 && b >= 0 && a < G::LWI && b < G::LHI) return lum[b * G::LWI + a];
+                    return luma_at(px, seed, i, j);                       // outside the staged luma (tiny images)
+                };
+                const float c0 = L(ip, jp), c1 = L(ip, jm), c2 = L(im, jp), c3 = L(im, jm);
+                v = fx * (fy * c0 + (1.0f - fy) * c1) + (1.0f - fx) * (fy * c2 + (1.0f - fy) * c3);
+            }
             lds[idx] = v;
         }
+    } else {
+        for (int idx = tid; idx < G::LH * G::LW; idx += NTHR) {
+            const int ly = idx / G::LW, lx = idx - ly * G::LW;
+            const int sx = symm(x0 - G::RP + lx, w), sy = symm(y0 - R + ly, h);
+            lds[idx] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : in[(size_t)sy * w + sx];
+        }
     }
+    const VTaps<G::NT> tw(wt);
     __syncthreads();
 
-    // ---- phase 1: horizontal pass, in place.  A row's 32 items sit in one half-wave, so every
-    // lane's reads of the row are issued before any lane's write of it (in-order LDS per wave).
-    for (int item = tid; item < G::LH * (G::TW / 4); item += 256) {
+    for (int item = tid; item < G::LH * (G::TW / 4); item += NTHR) {
         const int row = item >> 5, c4 = (item & 31) * 4;
         float *rowp = lds + row * G::LW;
         float v[4 + 2 * G::RP];
+        const lds_cv_f32x4 *rp4 = (const lds_cv_f32x4 *)(rowp + c4);
 #pragma unroll
         for (int m = 0; m < (4 + 2 * G::RP) / 4; m++) {
-            const float4 t = *reinterpret_cast<const float4 *>(rowp + c4 + 4 * m);
+            const f32x4 t = rp4[m];
             v[4 * m + 0] = t.x; v[4 * m + 1] = t.y; v[4 * m + 2] = t.z; v[4 * m + 3] = t.w;
         }
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < G::NT; i++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] = fmaf(wt.w[i], v[(G::RP - R) + k + i], acc[k]);
+            for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(G::RP - R) + k + i], acc[k]);
         }
         *reinterpret_cast<float4 *>(rowp + G::RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
 
-    // ---- phase 2: vertical pass, 4 columns x RB rows per lane, taps in increasing order --------
-    {
-        const int cg = tid & 31, rg = tid >> 5;
+    for (int item = tid; item < G::V_ITEMS; item += NTHR) {
+        const int cg = item & 31, rg = item >> 5;
         const float *colp = lds + (rg * G::RB) * G::LW + G::RP + cg * 4;
         float4 acc[G::RB];
 #pragma unroll
         for (int rr = 0; rr < G::RB; rr++) acc[rr] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int k = 0; k < G::RB + 2 * R; k++) {
+            // bound the live ranges: without this fence hipcc hoists all RB+2R row reads (120+ VGPRs)
+            if (KCH > 0 && k > 0 && (k % KCH) == 0) __builtin_amdgcn_sched_barrier(0);
             const float4 v = *reinterpret_cast<const float4 *>(colp + k * G::LW);
 #pragma unroll
             for (int rr = 0; rr < G::RB; rr++) {
                 const int i = k - rr;
                 if (i >= 0 && i < G::NT) {
-                    acc[rr].x = fmaf(wt.w[i], v.x, acc[rr].x);
-                    acc[rr].y = fmaf(wt.w[i], v.y, acc[rr].y);
-                    acc[rr].z = fmaf(wt.w[i], v.z, acc[rr].z);
-                    acc[rr].w = fmaf(wt.w[i], v.w, acc[rr].w);
+                    acc[rr].x = fmaf(tw.w[i], v.x, acc[rr].x);
+                    acc[rr].y = fmaf(tw.w[i], v.y, acc[rr].y);
+                    acc[rr].z = fmaf(tw.w[i], v.z, acc[rr].z);
+                    acc[rr].w = fmaf(tw.w[i], v.w, acc[rr].w);
                 }
             }
         }
@@ -190,6 +257,14 @@ __global__ __launch_bounds__(256) void blur_layer_kernel(const float *__restrict
         }
     }
 }
+
+// Shipping geometry (tools/ubench/blur_variants.hip on 8 x 3840x2160, MI355X): 128 x 32 tiles, 256
+// threads, 4 output rows per lane in the vertical pass, XCD-aware 1-D tile order.
+template <int R>
+struct BlurShip {
+    static constexpr int TH = 32, NTHR = 256, RB = 4;
+    using G = Blur2Geom<R, TH, NTHR, 4, RB>;
+};
 
 // NearestNeighborDownScale.metal:15-22: out[y][x] = in[2y][2x] (previous octave's layer nspo)
 __global__ __launch_bounds__(256) void downsample_kernel(const float *__restrict__ src, float *__restrict__ dst,

@@ -66,84 +66,121 @@ __device__ __forceinline__ const float *layer_ptr(const PyramidDesc &p, int fram
 
 // ------------------------------------------------------------------------------------------------
 // Extrema: Sources/MetalShaders/Metal/SIFTExtrema.metal:62-110.
-// One lane per column, each workgroup walks EH rows with a 3-row sliding window of DoG values for
-// all nspo+2 layers held in registers.  Strict test against neighbours 1..25 of the reference's
+// One lane per column; a wavefront covers 62 output columns (lanes 0 and 63 are halo) so that the
+// x-1 / x+1 neighbours come from cross-lane shuffles instead of extra loads: per row and Gaussian
+// layer ONE coalesced load.  Each workgroup walks EH rows with a 3-row sliding window of DoG values
+// for all nspo+2 layers in registers.  Strict test against neighbours 1..25 of the reference's
 // 26-entry table (entry 0 = (-1,-1,-1) skipped unless full_neighbourhood).  The soft-threshold /
 // border pre-filter that the reference applies at refinement entry (SIFTInterpolate.metal:208,
 // :223) is applied at emission so that noise extrema never reach the list; raw_count still counts
 // every strict extremum.
+constexpr int EXT_COLS_PER_WAVE = 62, EXT_COLS_PER_BLOCK = 4 * EXT_COLS_PER_WAVE;
+
 template <int NS>
 __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParams prm, int o, int EH,
                                                      ExtremumRec *__restrict__ lists, int32_t *__restrict__ cand_count,
                                                      int32_t *__restrict__ raw_count) {
     constexpr int ND = NS + 2;
+    // Workgroup-level staging (as the reference's threadgroup array, SIFTExtrema.metal:71-75, 101-109):
+    // one global atomic per workgroup and counter.  A single device-scope counter serialises at
+    // ~12 ns per atomic on MI355X, which at one atomic per extremum cost more than the whole scan.
+    constexpr int STAGE = 1024;
+    __shared__ ExtremumRec stage[STAGE];
+    __shared__ int s_cand, s_raw, s_base;
+    if (threadIdx.x == 0) { s_cand = 0; s_raw = 0; }
+    __syncthreads();
     const int w = P.w[o], h = P.h[o];
     const int frame = blockIdx.z, group = frame * P.n_octaves + o;
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * EXT_COLS_PER_BLOCK + wv * EXT_COLS_PER_WAVE + lane;      // lane 0 = column x0-1 ... (first output column is 1)
     const int ya = blockIdx.y * EH + 1;                    // first output row of this block
     const int yb = min(ya + EH, h - 1);                    // one past the last output row
-    if (ya >= yb) return;
+    if (ya >= yb || w < 3) return;                         // uniform for the workgroup
     const size_t n = (size_t)w * h;
     const float *g0 = layer_ptr(P, frame, o, 0);
-    const bool active = (x >= 1 && x <= w - 2);
-    const int xc = min(max(x, 1), max(w - 2, 1));          // clamped column so edge lanes load safely
-    if (w < 3) return;
+    ExtremumRec *glist = lists + (size_t)frame * P.ext_frame + P.ext_off[o];
+    const bool active = (lane >= 1 && lane <= 62 && x >= 1 && x <= w - 2);
+    const int xc = min(x, w - 1);                          // clamped column so out-of-image lanes load safely
 
-    float d[3][ND][3];
+    // window rows as separate arrays so that rotating them is a renaming (3x unrolled loop), not 45 moves
+    float ra[ND][3], rb[ND][3], rc[ND][3];
     auto load_row = [&](int y, float (&row)[ND][3]) {
-        float gprev[3], gcur[3];
         const float *p = g0 + (size_t)y * w + xc;
-        gprev[0] = p[-1]; gprev[1] = p[0]; gprev[2] = p[1];
+        float gprev = p[0];
 #pragma unroll
         for (int l = 0; l < ND; l++) {
-            const float *q = p + (size_t)(l + 1) * n;
-            gcur[0] = q[-1]; gcur[1] = q[0]; gcur[2] = q[1];
-#pragma unroll
-            for (int c = 0; c < 3; c++) { row[l][c] = gcur[c] - gprev[c]; gprev[c] = gcur[c]; }
+            const float gcur = p[(size_t)(l + 1) * n];
+            const float dv = gcur - gprev;
+            gprev = gcur;
+            row[l][1] = dv;
+            row[l][0] = __shfl_up(dv, 1);
+            row[l][2] = __shfl_down(dv, 1);
         }
     };
-    load_row(ya - 1, d[0]);
-    load_row(ya, d[1]);
     const float pre = prm.dog_threshold * 0.8f;
     const int border = prm.border;
-    for (int y = ya; y < yb; y++) {
-        load_row(y + 1, d[2]);
+    const bool full = prm.full_neighbourhood != 0;
+    // value < min(all) / value > max(all) over the reference's neighbour list, evaluated separably:
+    // per (layer, row) the max/min of the three columns, with the centre excluded in (s, mid) and
+    // table entry 0 = (x-1, y-1, s-1) excluded in (s-1, top) unless full_neighbourhood.  min/max are
+    // exact, so the grouping does not change the result.
+    auto test_row = [&](int y, const float (&top)[ND][3], const float (&mid)[ND][3], const float (&bot)[ND][3]) {
+        float M[3][ND], m[3][ND];
+#pragma unroll
+        for (int l = 0; l < ND; l++) {
+            M[0][l] = fmaxf(fmaxf(top[l][0], top[l][1]), top[l][2]); m[0][l] = fminf(fminf(top[l][0], top[l][1]), top[l][2]);
+            M[1][l] = fmaxf(fmaxf(mid[l][0], mid[l][1]), mid[l][2]); m[1][l] = fminf(fminf(mid[l][0], mid[l][1]), mid[l][2]);
+            M[2][l] = fmaxf(fmaxf(bot[l][0], bot[l][1]), bot[l][2]); m[2][l] = fminf(fminf(bot[l][0], bot[l][1]), bot[l][2]);
+        }
 #pragma unroll
         for (int s = 1; s <= NS; s++) {
-            const float v = d[1][s][1];
-            float mn = +1000.0f, mx = -1000.0f;
-#pragma unroll
-            for (int dz = -1; dz <= 1; dz++)
-#pragma unroll
-                for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; dx++) {
-                        if (dx == 0 && dy == 0 && dz == 0) continue;
-                        const float nv = d[1 + dy][s + dz][1 + dx];
-                        if (dx == -1 && dy == -1 && dz == -1) {        // table entry 0
-                            if (prm.full_neighbourhood) { mn = fminf(mn, nv); mx = fmaxf(mx, nv); }
-                        } else {
-                            mn = fminf(mn, nv); mx = fmaxf(mx, nv);
-                        }
-                    }
+            const float v = mid[s][1];
+            const float q_mx = full ? M[0][s - 1] : fmaxf(top[s - 1][1], top[s - 1][2]);
+            const float q_mn = full ? m[0][s - 1] : fminf(top[s - 1][1], top[s - 1][2]);
+            float mx = fmaxf(fmaxf(q_mx, M[1][s - 1]), M[2][s - 1]);
+            float mn = fminf(fminf(q_mn, m[1][s - 1]), m[2][s - 1]);
+            mx = fmaxf(fmaxf(mx, M[0][s]), M[2][s]);
+            mn = fminf(fminf(mn, m[0][s]), m[2][s]);
+            mx = fmaxf(fmaxf(mx, mid[s][0]), mid[s][2]);
+            mn = fminf(fminf(mn, mid[s][0]), mid[s][2]);
+            mx = fmaxf(fmaxf(mx, M[0][s + 1]), fmaxf(M[1][s + 1], M[2][s + 1]));
+            mn = fminf(fminf(mn, m[0][s + 1]), fminf(m[1][s + 1], m[2][s + 1]));
+            mx = fmaxf(mx, -1000.0f); mn = fminf(mn, +1000.0f);           // sentinels, SIFTExtrema.metal:81-82
             const bool ext = active && ((v < mn) || (v > mx));
             if (ext) {
-                atomicAdd(&raw_count[group], 1);
+                atomicAdd(&s_raw, 1);
                 const bool oob = x < border || x > w - border - 1 || y < border || y > h - border - 1;
                 if (fabsf(v) > pre && !oob) {
-                    const int idx = atomicAdd(&cand_count[group], 1);
-                    if (idx < P.cap_ext[o]) {
-                        ExtremumRec e; e.x = x; e.y = y; e.scale = s;
-                        lists[(size_t)frame * P.ext_frame + P.ext_off[o] + idx] = e;
+                    ExtremumRec e; e.x = x; e.y = y; e.scale = s;
+                    const int li = atomicAdd(&s_cand, 1);
+                    if (li < STAGE) {
+                        stage[li] = e;
+                    } else {                                              // staging full (very dense input): direct append
+                        const int idx = atomicAdd(&cand_count[group], 1);
+                        if (idx < P.cap_ext[o]) glist[idx] = e;
                     }
                 }
             }
         }
-#pragma unroll
-        for (int l = 0; l < ND; l++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) { d[0][l][c] = d[1][l][c]; d[1][l][c] = d[2][l][c]; }
+    };
+    load_row(ya - 1, ra);
+    load_row(ya, rb);
+    for (int y = ya; y < yb; y += 3) {
+        load_row(y + 1, rc);
+        test_row(y, ra, rb, rc);
+        if (y + 1 < yb) { load_row(y + 2, ra); test_row(y + 1, rb, rc, ra); }
+        if (y + 2 < yb) { load_row(y + 3, rb); test_row(y + 2, rc, ra, rb); }
     }
+    __syncthreads();
+    const int nloc = min(s_cand, STAGE);
+    if (threadIdx.x == 0) {
+        if (s_raw) atomicAdd(&raw_count[group], s_raw);
+        s_base = nloc ? atomicAdd(&cand_count[group], nloc) : 0;
+    }
+    __syncthreads();
+    const int base = s_base;
+    for (int i = threadIdx.x; i < nloc; i += 256)
+        if (base + i < P.cap_ext[o]) glist[base + i] = stage[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,6 +266,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
                                                     const ExtremumRec *__restrict__ lists, const int32_t *__restrict__ cand_count,
                                                     KeypointRec *__restrict__ kp_tmp, unsigned long long *__restrict__ kp_keys,
                                                     int32_t *__restrict__ kp_count) {
+    __shared__ int s_n, s_base;
     const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(cand_count[group], P.cap_ext[o]);
     const int w = P.w[o], h = P.h[o];
@@ -236,55 +274,70 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
     const float delta = P.delta[o];
     const float sigmaRatio = P.sigma1[o] / P.sigma0[o];
     const ExtremumRec *list = lists + (size_t)frame * P.ext_frame + P.ext_off[o];
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
-        const ExtremumRec e = list[k];
-        int x = e.x, y = e.y, s = e.scale;
-        float value = t.rd(x, y, s);
-        if (fabsf(value) <= prm.dog_threshold * 0.8f) continue;
-        if (out_of_bounds(x, y, s, w, h, P.nspo, prm.border)) continue;
-        bool converged = false, dropped = false;
-        float alpha[3] = {0.0f, 0.0f, 0.0f};
-        int i = 0;
-        while (i < prm.max_iterations) {
-            interpolation_step(t, x, y, s, alpha);
-            if (fabsf(alpha[0]) < prm.max_offset && fabsf(alpha[1]) < prm.max_offset && fabsf(alpha[2]) < prm.max_offset) {
-                converged = true;
-                break;
+    for (int k0 = blockIdx.x * 256; k0 < n; k0 += gridDim.x * 256) {      // uniform trip count per workgroup
+        const int k = k0 + threadIdx.x;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        bool keep = false;
+        KeypointRec r;
+        unsigned long long key = 0;
+        if (k < n) {
+            const ExtremumRec e = list[k];
+            int x = e.x, y = e.y, s = e.scale;
+            float value = t.rd(x, y, s);
+            bool ok = !(fabsf(value) <= prm.dog_threshold * 0.8f) && !out_of_bounds(x, y, s, w, h, P.nspo, prm.border);
+            bool converged = false;
+            float alpha[3] = {0.0f, 0.0f, 0.0f};
+            int i = 0;
+            while (ok && i < prm.max_iterations) {
+                interpolation_step(t, x, y, s, alpha);
+                if (fabsf(alpha[0]) < prm.max_offset && fabsf(alpha[1]) < prm.max_offset && fabsf(alpha[2]) < prm.max_offset) {
+                    converged = true;
+                    break;
+                }
+                if (alpha[0] > +prm.max_offset) x += 1;
+                if (alpha[0] < -prm.max_offset) x -= 1;
+                if (alpha[1] > +prm.max_offset) y += 1;
+                if (alpha[1] < -prm.max_offset) y -= 1;
+                if (alpha[2] > +prm.max_offset) s += 1;
+                if (alpha[2] < -prm.max_offset) s -= 1;
+                if (out_of_bounds(x, y, s, w, h, P.nspo, prm.border)) ok = false;
+                i += 1;
             }
-            if (alpha[0] > +prm.max_offset) x += 1;
-            if (alpha[0] < -prm.max_offset) x -= 1;
-            if (alpha[1] > +prm.max_offset) y += 1;
-            if (alpha[1] < -prm.max_offset) y -= 1;
-            if (alpha[2] > +prm.max_offset) s += 1;
-            if (alpha[2] < -prm.max_offset) s -= 1;
-            if (out_of_bounds(x, y, s, w, h, P.nspo, prm.border)) { dropped = true; break; }
-            i += 1;
+            ok = ok && converged;
+            if (ok) {
+                float dD[3];
+                derivatives3d(t, x, y, s, dD);
+                const float cx = dD[0] * alpha[0];                  // :96-99 x term only
+                value = t.rd(x, y, s) + cx * 0.5f;
+                ok = !(fabsf(value) <= prm.dog_threshold) && !is_on_edge(t, x, y, s, prm.edge_threshold);
+            }
+            if (ok) {
+                keep = true;                                        // SIFTOctave.swift:266-284
+                r.octave = o; r.scale = s; r.sub_scale = alpha[2];
+                r.x = x; r.y = y;
+                r.abs_x = ((float)x + alpha[0]) * delta;
+                r.abs_y = ((float)y + alpha[1]) * delta;
+                r.norm_x = (float)x / (float)w;
+                r.norm_y = (float)y / (float)h;
+                r.sigma = P.sigmas[o][s] * powf(sigmaRatio, alpha[2]);
+                r.value = value;
+                const unsigned int kref = (unsigned int)((s * h + y) * w + x);
+                const unsigned int korg = (unsigned int)((e.scale * h + e.y) * w + e.x);
+                key = ((unsigned long long)kref << 32) | korg;
+            }
         }
-        if (dropped || !converged) continue;
-        {
-            float dD[3];
-            derivatives3d(t, x, y, s, dD);
-            const float cx = dD[0] * alpha[0];                  // :96-99 x term only
-            value = t.rd(x, y, s) + cx * 0.5f;
+        // one global atomic per workgroup and iteration (a single hot counter serialises at ~12 ns/atomic)
+        const int li = keep ? atomicAdd(&s_n, 1) : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_n ? atomicAdd(&kp_count[group], s_n) : 0;
+        __syncthreads();
+        if (keep && s_base + li < P.cap_kp[o]) {
+            const size_t slot = (size_t)frame * P.kp_frame + P.kp_off[o] + s_base + li;
+            kp_tmp[slot] = r;
+            kp_keys[slot] = key;
         }
-        if (fabsf(value) <= prm.dog_threshold) continue;
-        if (is_on_edge(t, x, y, s, prm.edge_threshold)) continue;
-        const int idx = atomicAdd(&kp_count[group], 1);
-        if (idx >= P.cap_kp[o]) continue;
-        KeypointRec r;                                          // SIFTOctave.swift:266-284
-        r.octave = o; r.scale = s; r.sub_scale = alpha[2];
-        r.x = x; r.y = y;
-        r.abs_x = ((float)x + alpha[0]) * delta;
-        r.abs_y = ((float)y + alpha[1]) * delta;
-        r.norm_x = (float)x / (float)w;
-        r.norm_y = (float)y / (float)h;
-        r.sigma = P.sigmas[o][s] * powf(sigmaRatio, alpha[2]);
-        r.value = value;
-        const size_t slot = (size_t)frame * P.kp_frame + P.kp_off[o] + idx;
-        kp_tmp[slot] = r;
-        const unsigned int kref = (unsigned int)((s * h + y) * w + x);
-        const unsigned int korg = (unsigned int)((e.scale * h + e.y) * w + e.x);
-        kp_keys[slot] = ((unsigned long long)kref << 32) | korg;
+        __syncthreads();
     }
 }
 
@@ -318,11 +371,18 @@ __global__ __launch_bounds__(256) void sort_keypoints_kernel(PyramidDesc P, cons
 // reference -- and |grad| of central differences, mirror edges); outside the image -> (0, 0).
 __device__ __forceinline__ void gradient_at(const float *g, int w, int h, int gx, int gy, float &theta, float &mag) {
     if (gx < 0 || gy < 0 || gx >= w || gy >= h) { theta = 0.0f; mag = 0.0f; return; }
-    const int px = symm(gx + 1, w), mx = symm(gx - 1, w);
-    const int py = symm(gy + 1, h), my = symm(gy - 1, h);
-    auto rd = [&](int x, int y) -> float { return (x < 0 || y < 0 || x >= w || y >= h) ? 0.0f : g[(size_t)y * w + x]; };
-    const float tx = (rd(px, gy) - rd(mx, gy)) * 0.5f;
-    const float ty = (rd(gx, py) - rd(gx, my)) * 0.5f;
+    float tx, ty;
+    if (gx >= 1 && gy >= 1 && gx < w - 1 && gy < h - 1) {          // interior: no mirror
+        const float *p = g + (size_t)gy * w + gx;
+        tx = (p[1] - p[-1]) * 0.5f;
+        ty = (p[w] - p[-w]) * 0.5f;
+    } else {
+        const int px = symm(gx + 1, w), mx = symm(gx - 1, w);
+        const int py = symm(gy + 1, h), my = symm(gy - 1, h);
+        auto rd = [&](int x, int y) -> float { return (x < 0 || y < 0 || x >= w || y >= h) ? 0.0f : g[(size_t)y * w + x]; };
+        tx = (rd(px, gy) - rd(mx, gy)) * 0.5f;
+        ty = (rd(gx, py) - rd(gx, my)) * 0.5f;
+    }
     theta = atan2f(tx, ty);
     mag = sqrtf(tx * tx + ty * ty);
 }
@@ -476,9 +536,14 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
                                                         float *__restrict__ desc_f32 /* may be null */) {
-    __shared__ float patch_all[4][DESC_N];
+    // NCOPY private copies of the 4x4x8 histogram per wave (copy = lane % NCOPY): neighbouring lanes
+    // take neighbouring samples, which mostly fall into the same cell and bin, so a single histogram
+    // serialises the ds_add_f32 of a wave-instruction many ways.  Copies are summed in a fixed order.
+    constexpr int NCOPY = 16;
+    __shared__ float patch_all[4][NCOPY][DESC_N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float *patch = patch_all[wv];
+    float *patch = patch_all[wv][lane & (NCOPY - 1)];
+    float *patch0 = patch_all[wv][0];
     const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(desc_count[group], P.cap_desc[o]);
     const int w = P.w[o], h = P.h[o];
@@ -504,16 +569,24 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
         const float histogramWidth = 3.0f * sc;
         const int radius = (int)(histogramWidth * sqrtf(2.0f) * ((float)d + 1.0f) * 0.5f + 0.5f);
 
-        patch[lane] = 0.0f; patch[lane + 64] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCOPY * DESC_N / 64; c++) patch0[c * 64 + lane] = 0.0f;   // all copies (contiguous)
         __builtin_amdgcn_wave_barrier();
         const int side = 2 * radius + 1, total = side * side;
+        // sample idx -> (j = idx / side - radius, i = idx % side - radius), advanced incrementally
+        int jj = lane / side, ii = lane - jj * side;
+        const int dj = 64 / side, di_ = 64 - dj * side;
         for (int idx = lane; idx < total; idx += 64) {
-            const int jj = idx / side, ii = idx - jj * side;
-            const int j = jj - radius, i = ii - radius;                   // j outer (x offset), i inner (y offset)
+            const int j = jj - radius, i = ii - radius;                   // j: x offset (outer), i: y offset (inner)
+            ii += di_; jj += dj;
+            if (ii >= side) { ii -= side; jj += 1; }
             const float rx = ((float)j * cosT - (float)i * sinT) / histogramWidth;
             const float ry = ((float)j * sinT + (float)i * cosT) / histogramWidth;
             const float bx = rx + (float)(d / 2) - 0.5f;
             const float by = ry + (float)(d / 2) - 0.5f;
+            // every trilinear corner of this sample lies outside the 4x4 grid (addValue :66-68 drops
+            // all 8 contributions): nothing to add, skip the gradient entirely
+            if (bx <= -1.0f || bx >= 4.0f || by <= -1.0f || by >= 4.0f) continue;
             const float fx = truncf(px + (float)j), fy = truncf(py + (float)i);   // ushort2(px + j, py + i)
             float gth = 0.0f, gm = 0.0f;
             if (fx >= 0.0f && fy >= 0.0f && fx < (float)w && fy < (float)h) gradient_at(g, w, h, (int)fx, (int)fy, gth, gm);
@@ -544,7 +617,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        float f0 = patch[lane], f1 = patch[lane + 64];
+        float f0 = patch0[lane], f1 = patch0[64 + lane];
+#pragma unroll
+        for (int c = 1; c < NCOPY; c++) { f0 += patch0[c * DESC_N + lane]; f1 += patch0[c * DESC_N + 64 + lane]; }
         {   // normalise -> clamp 0.2 -> normalise (:15-39, :224-227)
             float dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));
             f0 *= dn; f1 *= dn;

@@ -299,10 +299,12 @@ static void t_collect(siftmi_ctx *c) {
 template <int R, bool SEED>
 static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
                                 const TapWeights &wt, const SeedSource &seed) {
-    using Gm = BlurGeom<R>;
-    dim3 grid((w + Gm::TW - 1) / Gm::TW, (h + Gm::TH - 1) / Gm::TH, nf);
-    hipLaunchKernelGGL((blur_layer_kernel<R, SEED>), grid, dim3(256), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
-                       c->frame_stride, wt, seed);
+    using S = BlurShip<R>;
+    using Gm = typename S::G;
+    const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + Gm::TH - 1) / Gm::TH) * nf;
+    dim3 grid(((total + 7) / 8) * 8, 1, 1);          // XCD-aware 1-D tile order, see blur2_kernel
+    hipLaunchKernelGGL((blur2_kernel<R, S::TH, S::NTHR, 4, S::RB, SEED, 1, 0, true>), grid, dim3(S::NTHR), SEED ? Gm::seed_lds_bytes : Gm::lds_bytes, st, src, dst, w, h,
+                       c->frame_stride, c->frame_stride, wt, seed, nf);
     return hipGetLastError();
 }
 
@@ -357,11 +359,11 @@ enum { C_RAW = 0, C_CAND = 1, C_KP = 2, C_ORIENTED = 3, C_DESC = 4 };
 // extrema -> refine -> sort  (SIFT.swift:147-202)
 static int run_detect(siftmi_ctx *c, hipStream_t st, int nf) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 5 * (size_t)c->B * c->n_oct * sizeof(int32_t), st));
-    const int EH = 16;
+    const int EH = 33;                                  // multiple of 3: the row loop is unrolled 3x
     for (int o = 0; o < c->n_oct; o++) {
         if (c->ow[o] < 3 || c->oh[o] < 3) continue;
         t_begin(c, SIFTMI_T_EXTREMA);
-        dim3 grid((c->ow[o] + 255) / 256, (c->oh[o] - 2 + EH - 1) / EH, nf);
+        dim3 grid((c->ow[o] - 2 + EXT_COLS_PER_BLOCK - 1) / EXT_COLS_PER_BLOCK, (c->oh[o] - 2 + EH - 1) / EH, nf);
 #define LAUNCH_EXT(NS) hipLaunchKernelGGL((extrema_kernel<NS>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW))
         switch (c->nspo) {
             case 1: LAUNCH_EXT(1); break;

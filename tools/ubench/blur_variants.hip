@@ -1,0 +1,97 @@
+// Standalone harness: times Gaussian-layer blur kernel variants on 8 x 3840x2160 f32 frames and checks
+// every variant bit-for-bit against a naive kernel (same tap order, fmaf).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I../../siftmetal_amd/csrc -o blur_variants blur_variants.hip
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "dense_kernels.hip.h"
+using namespace siftmi;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ void naive_x(const float *in, float *out, int w, int h, TapWeights wt, int n) {
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y; if (x >= w) return;
+    in += (size_t)blockIdx.z * w * h; out += (size_t)blockIdx.z * w * h;
+    float s = 0; int o = x - n / 2;
+    for (int i = 0; i < n; i++) { int xx = symm(o + i, w); s = fmaf(wt.w[i], in[(size_t)y * w + xx], s); }
+    out[(size_t)y * w + x] = s;
+}
+__global__ void naive_y(const float *in, float *out, int w, int h, TapWeights wt, int n) {
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y; if (x >= w) return;
+    in += (size_t)blockIdx.z * w * h; out += (size_t)blockIdx.z * w * h;
+    float s = 0; int o = y - n / 2;
+    for (int i = 0; i < n; i++) { int yy = symm(o + i, h); s = fmaf(wt.w[i], in[(size_t)yy * w + x], s); }
+    out[(size_t)y * w + x] = s;
+}
+
+static int gw(float s, TapWeights &out) {
+    int radius = (int)std::ceil(4.0f * s), size = 2 * radius + 1; float t = 0, ss = s * s;
+    for (int k = -radius, i = 0; k <= radius; k++, i++) { float w = std::exp(-0.5f * ((float)(k * k) / ss)); out.w[i] = w; t += w; }
+    for (int i = 0; i < size; i++) out.w[i] /= t;
+    for (int i = size; i < 32; i++) out.w[i] = 0;
+    return size;
+}
+
+struct Ctx { float *src, *dst, *ref, *tmp; int w, h, nf; size_t n; };
+
+static const char *g_filter = nullptr; static int g_rfilter = 0;
+template <typename F>
+static void run_variant(const char *name, Ctx &c, int R, F launch) {
+    if (g_filter && !strstr(name, g_filter)) return;
+    if (g_rfilter && R != g_rfilter) return;
+    CHECK(hipMemset(c.dst, 0xff, c.n * c.nf * 4));
+    launch();
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> a(c.n), b(c.n);
+    size_t bad = 0;
+    for (int f : {0, c.nf - 1}) {
+        CHECK(hipMemcpy(a.data(), c.dst + (size_t)f * c.n, c.n * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(b.data(), c.ref + (size_t)f * c.n, c.n * 4, hipMemcpyDeviceToHost));
+        bad += memcmp(a.data(), b.data(), c.n * 4) != 0;
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) launch();
+    hipEventRecord(e0);
+    const int iters = 20;
+    for (int i = 0; i < iters; i++) launch();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("  %-34s R=%2d taps=%2d  %.4f ms  %7.1f GB/s  %s\n", name, R, 2 * R + 1, ms, 8.0 * c.n * c.nf / (ms * 1e-3) / 1e9, bad ? "MISMATCH" : "exact");
+    fflush(stdout);
+}
+
+template <int R>
+static void bench_R(Ctx &c, float rho) {
+    TapWeights wt; int n = gw(rho, wt);
+    if (n != 2 * R + 1) { printf("rho %f gives %d taps, expected %d\n", rho, n, 2 * R + 1); return; }
+    dim3 g((c.w + 255) / 256, c.h, c.nf);
+    hipLaunchKernelGGL(naive_x, g, dim3(256), 0, 0, c.src, c.tmp, c.w, c.h, wt, n);
+    hipLaunchKernelGGL(naive_y, g, dim3(256), 0, 0, c.tmp, c.ref, c.w, c.h, wt, n);
+    CHECK(hipDeviceSynchronize());
+    SeedSource none; memset(&none, 0, sizeof(none));
+#define V2(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
+        dim3 grid((c.w + G::TW - 1) / G::TW, (c.h + G::TH - 1) / G::TH, c.nf); \
+        run_variant("v2 TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " kch=" #KCH_, c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf); }); }
+#define V2X(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
+        const int total = ((c.w + G::TW - 1) / G::TW) * ((c.h + G::TH - 1) / G::TH) * c.nf; \
+        dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("v2x TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf); }); }
+    V2(32, 256, 4, 1, 0) V2X(32, 256, 4, 1, 0) V2(64, 512, 4, 1, 0) V2X(64, 512, 4, 1, 0) V2X(64, 256, 8, 1, 0) V2X(16, 256, 2, 1, 0)
+}
+
+int main(int argc, char **argv) {
+    Ctx c; c.w = argc > 1 ? atoi(argv[1]) : 3840; c.h = argc > 2 ? atoi(argv[2]) : 2160; c.nf = argc > 3 ? atoi(argv[3]) : 8;
+    c.n = (size_t)c.w * c.h;
+    if (argc > 4) g_rfilter = atoi(argv[4]);
+    if (argc > 5) g_filter = argv[5];
+    CHECK(hipMalloc(&c.src, c.n * c.nf * 4)); CHECK(hipMalloc(&c.dst, c.n * c.nf * 4));
+    CHECK(hipMalloc(&c.ref, c.n * c.nf * 4)); CHECK(hipMalloc(&c.tmp, c.n * c.nf * 4));
+    std::vector<float> h(c.n * c.nf);
+    unsigned s = 12345; for (auto &v : h) { s = s * 1664525u + 1013904223u; v = (s >> 8) * (1.0f / 16777216.0f); }
+    CHECK(hipMemcpy(c.src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    printf("%dx%d x %d frames\n", c.w, c.h, c.nf);
+    bench_R<5>(c, 1.2263f); bench_R<7>(c, 1.5450f); bench_R<8>(c, 1.9466f); bench_R<10>(c, 2.4525f); bench_R<13>(c, 3.0900f);
+    return 0;
+}
