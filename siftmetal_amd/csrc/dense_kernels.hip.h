@@ -240,6 +240,10 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
                 }
             }
         }
+        // pin the accumulators here: otherwise LLVM sinks each row's whole FMA chain into the
+        // `gy < h` store guard below, which keeps all RB+2R loaded rows live (120+ VGPRs)
+#pragma unroll
+        for (int rr = 0; rr < G::RB; rr++) asm volatile("" : "+v"(acc[rr].x), "+v"(acc[rr].y), "+v"(acc[rr].z), "+v"(acc[rr].w));
         const int gx = x0 + cg * 4;
 #pragma unroll
         for (int rr = 0; rr < G::RB; rr++) {
@@ -254,6 +258,185 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
                 if (gx + 2 < w) o[2] = acc[rr].z;
                 if (gx + 3 < w) o[3] = acc[rr].w;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Marching form of the layer blur (the shipping kernel for the Gaussian layers).  A workgroup owns a
+// 128-column strip and walks down SPC steps of S = 32 rows.  LDS holds S + 2R rows: the last 2R
+// horizontally blurred rows of the previous step are carried over (copied to the top through
+// registers), so the horizontal pass runs once per image row (the tile kernel recomputes it
+// (S+2R)/S = 1.8x at R = 13) and every input row is fetched once per strip; the next step's S input
+// rows are prefetched into registers while this step computes (loads overlap the FMA phases).
+// Same arithmetic, same tap order: bit-identical to blur2_kernel and to the oracle.
+template <int R>
+struct MarchGeom {
+    static constexpr int RP = (R + 3) & ~3;
+    static constexpr int TW = 128, S = 32, NTHR = 256, RB = 4;
+    static constexpr int LW = TW + 2 * RP, LH = S + 2 * R, NT = 2 * R + 1;
+    static constexpr int V = LW / 4;                                    // float4 per staged row
+    static constexpr int NPF = (S * V + NTHR - 1) / NTHR;               // prefetch float4 per lane
+    static constexpr int NCARRY = (2 * R * (TW / 4) + NTHR - 1) / NTHR; // carried float4 per lane
+    static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
+};
+
+template <int R, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
+                                                              int n_frames, int spc /* steps per chunk */) {
+    using G = MarchGeom<R>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    // XCD-aware 1-D order (see blur2_kernel): frame, chunk, strip with the strip index fastest
+    const int tx = (w + G::TW - 1) / G::TW;
+    const int ch_rows = spc * G::S;
+    const int nch = (h + ch_rows - 1) / ch_rows;
+    const int total = tx * nch * n_frames;
+    const int per_xcd = (total + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= total) return;
+    const int frame = t / (tx * nch);
+    const int rem = t - frame * (tx * nch);
+    const int chunk = rem / tx, bx = rem - chunk * tx;
+    const int x0 = bx * G::TW, ybeg = chunk * ch_rows;
+    const float *__restrict__ in = src + (size_t)frame * src_frame_stride;
+    float *__restrict__ out = dst + (size_t)frame * dst_frame_stride;
+    const bool xin = (x0 - G::RP >= 0) && (x0 + G::TW + G::RP <= w) && (w & 3) == 0;   // columns need no mirror
+
+    // general staging of window rows [r0, r1) for a step whose first output row is y0 (mirror resolved)
+    auto stage_rows = [&](int y0s, int r0, int r1) {
+        for (int idx = r0 * G::LW + tid; idx < r1 * G::LW; idx += G::NTHR) {
+            const int ly = idx / G::LW, lx = idx - ly * G::LW;
+            const int sx = symm(x0 - G::RP + lx, w), sy = symm(y0s - R + ly, h);
+            lds[idx] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : in[(size_t)sy * w + sx];
+        }
+    };
+    // rows [y, y + n) of the strip need no mirror and are 16-byte aligned -> plain float4 loads
+    auto plain = [&](int y, int n) { return xin && y >= 0 && y + n <= h; };
+
+    // prologue: stage all LH rows of the first step
+    if (plain(ybeg - R, G::LH)) {
+        const float *base = in + (size_t)(ybeg - R) * w + (x0 - G::RP);
+        for (int idx = tid; idx < G::LH * G::V; idx += G::NTHR) {
+            const int ly = idx / G::V, lv = idx - ly * G::V;
+            *reinterpret_cast<float4 *>(lds + ly * G::LW + 4 * lv) = *reinterpret_cast<const float4 *>(base + (size_t)ly * w + 4 * lv);
+        }
+    } else {
+        stage_rows(ybeg, 0, G::LH);
+    }
+    const VTaps<G::NT> tw(wt);
+
+    for (int st = 0; st < spc; st++) {
+        const int y0 = ybeg + st * G::S;                     // first output row of this step
+        if (y0 >= h) break;                                  // uniform
+        const bool has_next = (st + 1 < spc) && (y0 + G::S < h);
+        // the S new input rows of the next step are image rows y0+S+R ... y0+2S+R-1
+        const bool pf_ok = has_next && plain(y0 + G::S + R, G::S);          // uniform
+        __syncthreads();                                     // B1: window rows are in LDS
+
+        // prefetch them into registers: the loads complete under the two FMA phases below
+        f32x4 pf[G::NPF];
+        if (pf_ok) {
+            const float *base = in + (size_t)(y0 + G::S + R) * w + (x0 - G::RP);
+#pragma unroll
+            for (int j = 0; j < G::NPF; j++) {
+                const int idx = tid + j * G::NTHR;
+                const int ly = idx / G::V, lv = idx - ly * G::V;
+                if ((j + 1) * G::NTHR <= G::S * G::V || idx < G::S * G::V)
+                    pf[j] = *reinterpret_cast<const f32x4 *>(base + (size_t)ly * w + 4 * lv);
+            }
+        }
+
+        // horizontal pass, in place (first step: all LH rows; later steps: only the S new rows)
+#pragma unroll 1
+        for (int item = (st == 0 ? 0 : 2 * R * 32) + tid; item < G::LH * 32; item += G::NTHR) {
+            const int row = item >> 5, c4 = (item & 31) * 4;
+            float *rowp = lds + row * G::LW;
+            float v[4 + 2 * G::RP];
+            const lds_cv_f32x4 *rp4 = (const lds_cv_f32x4 *)(rowp + c4);
+#pragma unroll
+            for (int m = 0; m < (4 + 2 * G::RP) / 4; m++) {
+                const f32x4 tv = rp4[m];
+                v[4 * m + 0] = tv.x; v[4 * m + 1] = tv.y; v[4 * m + 2] = tv.z; v[4 * m + 3] = tv.w;
+            }
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < G::NT; i++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(G::RP - R) + k + i], acc[k]);
+            }
+            *reinterpret_cast<float4 *>(rowp + G::RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();                                     // B2: blurred rows complete
+
+        // vertical pass: 4 columns x RB rows per lane, taps in increasing order
+        {
+            const int cg = tid & 31, rg = tid >> 5;
+            const float *colp = lds + (rg * G::RB) * G::LW + G::RP + cg * 4;
+            float4 acc[G::RB];
+#pragma unroll
+            for (int rr = 0; rr < G::RB; rr++) acc[rr] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int k = 0; k < G::RB + 2 * R; k++) {
+                if (k > 0 && (k & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // bound the load look-ahead (VGPRs)
+                const float4 v = *reinterpret_cast<const float4 *>(colp + k * G::LW);
+#pragma unroll
+                for (int rr = 0; rr < G::RB; rr++) {
+                    const int i = k - rr;
+                    if (i >= 0 && i < G::NT) {
+                        acc[rr].x = fmaf(tw.w[i], v.x, acc[rr].x);
+                        acc[rr].y = fmaf(tw.w[i], v.y, acc[rr].y);
+                        acc[rr].z = fmaf(tw.w[i], v.z, acc[rr].z);
+                        acc[rr].w = fmaf(tw.w[i], v.w, acc[rr].w);
+                    }
+                }
+            }
+            // pin the accumulators here: otherwise LLVM sinks each row's whole FMA chain into the
+            // `gy < h` store guard below, which keeps all RB+2R loaded rows live (120+ VGPRs)
+#pragma unroll
+            for (int rr = 0; rr < G::RB; rr++) asm volatile("" : "+v"(acc[rr].x), "+v"(acc[rr].y), "+v"(acc[rr].z), "+v"(acc[rr].w));
+            const int gx = x0 + cg * 4;
+#pragma unroll
+            for (int rr = 0; rr < G::RB; rr++) {
+                const int gy = y0 + rg * G::RB + rr;
+                if (gy >= h) continue;
+                float *o = out + (size_t)gy * w + gx;
+                if (gx + 3 < w && (w & 3) == 0) {
+                    *reinterpret_cast<float4 *>(o) = acc[rr];
+                } else {
+                    if (gx + 0 < w) o[0] = acc[rr].x;
+                    if (gx + 1 < w) o[1] = acc[rr].y;
+                    if (gx + 2 < w) o[2] = acc[rr].z;
+                    if (gx + 3 < w) o[3] = acc[rr].w;
+                }
+            }
+        }
+        if (!has_next) break;                                // uniform
+
+        // carry the last 2R blurred rows (window rows S ... S+2R-1, columns RP ... RP+TW-1) to the top
+        f32x4 cr[G::NCARRY];
+#pragma unroll
+        for (int j = 0; j < G::NCARRY; j++) {
+            const int idx = tid + j * G::NTHR;
+            if (idx < 2 * R * 32) cr[j] = *reinterpret_cast<const f32x4 *>(lds + (G::S + (idx >> 5)) * G::LW + G::RP + (idx & 31) * 4);
+        }
+        __syncthreads();                                     // B3: every read of this window is done
+#pragma unroll
+        for (int j = 0; j < G::NCARRY; j++) {
+            const int idx = tid + j * G::NTHR;
+            if (idx < 2 * R * 32) *reinterpret_cast<f32x4 *>(lds + (idx >> 5) * G::LW + G::RP + (idx & 31) * 4) = cr[j];
+        }
+        if (pf_ok) {
+#pragma unroll
+            for (int j = 0; j < G::NPF; j++) {
+                const int idx = tid + j * G::NTHR;
+                const int ly = idx / G::V, lv = idx - ly * G::V;
+                if ((j + 1) * G::NTHR <= G::S * G::V || idx < G::S * G::V)
+                    *reinterpret_cast<f32x4 *>(lds + (2 * R + ly) * G::LW + 4 * lv) = pf[j];
+            }
+        } else {
+            stage_rows(y0 + G::S, 2 * R, G::LH);             // border step: mirror path, straight to LDS
         }
     }
 }

@@ -78,7 +78,12 @@ static void bench_R(Ctx &c, float rho) {
         const int total = ((c.w + G::TW - 1) / G::TW) * ((c.h + G::TH - 1) / G::TH) * c.nf; \
         dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("v2x TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf); }); }
-    V2(32, 256, 4, 1, 0) V2X(32, 256, 4, 1, 0) V2(64, 512, 4, 1, 0) V2X(64, 512, 4, 1, 0) V2X(64, 256, 8, 1, 0) V2X(16, 256, 2, 1, 0)
+    V2X(32, 256, 4, 1, 0)
+#define VM(SPC_, MINW_) { using G = MarchGeom<R>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("march spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_); }); }
+    VM(1, 1) VM(4, 1) VM(8, 1) VM(17, 1) VM(8, 4) VM(8, 3)
 }
 
 int main(int argc, char **argv) {
