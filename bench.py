@@ -162,8 +162,20 @@ def main():
             ms = eng.time_blur(0, layer, 10)
             per_layer["o0_l%d_taps%d" % (layer, len(eng.weights(layer)))] = round(eng.blur_algorithmic_bytes(0) * eng.max_batch / (ms * 1e-3) / 1e9, 1)
         log("octave-0 blur GB/s by layer:", per_layer)
-        out["roofline"] = {"bound": "hbm", "kernel": "blur_layer_kernel<R> (Gaussian layer, fused X+Y)", "achieved": round(achieved, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        # HBM bytes per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/profile_round.sh)
+        traffic, traffic_src = None, None
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("blur_hbm_traffic_")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if prof:
+            pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+            ks = [k for k in pj["kernels"] if ", true, 1, 0, true>" not in k["kernel"]]        # layer kernels (not the seed variant)
+            if ks:
+                ratio = sum(k["hbm_bytes_per_launch_corrected"] for k in ks) / (pj["algorithmic_bytes_per_launch"] * len(ks))
+                traffic = int(ratio * total_bytes / max(blur_n, 1))
+                traffic_src = "profiles/%s: PMC bytes / algorithmic bytes = %.3f on the octave-0 launches, scaled to the average launch" % (prof[-1], ratio)
+        out["roofline"] = {"bound": "hbm", "kernel": "blur2_kernel<R> / blur_march_kernel<R> (one Gaussian layer, fused X+Y)", "achieved": round(achieved, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "launches": blur_n, "avg_launch_ms": round(blur_ms / max(blur_n, 1), 5),
                            "algorithmic_bytes_per_launch_avg": int(total_bytes / max(blur_n, 1)),
                            "octave0_GBps_by_layer": per_layer, "stage_ms_per_step": stage_ms,

@@ -76,7 +76,10 @@ typedef struct siftmi_config {
     int32_t max_keypoints;
     int32_t max_descriptors;
     int32_t keep_descriptor_floats;     /* 1 = also keep the 128 pre-quantisation floats          */
-    int32_t reserved[7];
+    int32_t use_hip_graph;              /* 1 (default) = siftmi_detect_describe_batch_device captures its
+                                           launch sequence into a hipGraph and replays it while the
+                                           caller keeps passing the same buffers                    */
+    int32_t reserved[6];
 } siftmi_config;
 
 /* Replaces SIFTExtremaResult (Sources/MetalShaders/include/SIFTExtrema.h:14-18). */

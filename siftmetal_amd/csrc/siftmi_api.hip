@@ -90,6 +90,17 @@ struct siftmi_ctx {
     bool pyramid_valid = false;
     PyramidDesc P;
     DetectParams prm;
+    // hipGraph cache of the batched device path (one call signature)
+    struct GraphKey {
+        const void *px; int n_frames, format; size_t row_stride, frame_stride; void *kp; long long kp_cap; void *desc; long long desc_cap;
+        void *counts, *totals; hipStream_t st;
+        bool operator==(const GraphKey &o) const {
+            return px == o.px && n_frames == o.n_frames && format == o.format && row_stride == o.row_stride && frame_stride == o.frame_stride &&
+                   kp == o.kp && kp_cap == o.kp_cap && desc == o.desc && desc_cap == o.desc_cap && counts == o.counts && totals == o.totals && st == o.st;
+        }
+    } gkey{};
+    hipGraphExec_t gexec = nullptr;
+    bool graph_failed = false;
     // timings
     bool timing = false;
     std::vector<EventPair> pending, pool;
@@ -134,6 +145,7 @@ extern "C" int siftmi_default_config(siftmi_config *cfg, int32_t width, int32_t 
     cfg->descriptor_scales_per_octave = 3;   // SIFTOctave.swift:398
     cfg->full_neighbourhood = 0;
     cfg->max_batch = 1;
+    cfg->use_hip_graph = 1;
     return SIFTMI_OK;
 }
 
@@ -154,6 +166,7 @@ static void free_ctx(siftmi_ctx *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -454,6 +467,25 @@ static int check_format(siftmi_ctx *c, int format, size_t row_stride) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// the launch sequence of one batched call (all sub-batches); everything asynchronous on `st`
+static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const void *d_pixels, int format, size_t row_stride,
+                         size_t frame_stride, KeypointRec *d_kp, long long kp_cap, DescriptorRec *d_desc, long long desc_cap,
+                         int32_t *d_counts, int32_t *d_totals) {
+    int rc;
+    HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
+    for (int f0 = 0; f0 < n_frames; f0 += c->B) {
+        const int nf = std::min(c->B, n_frames - f0);
+        const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
+        if ((rc = run_dense(c, st, nf, px, format, row_stride, frame_stride))) return rc;
+        if ((rc = run_detect(c, st, nf))) return rc;
+        if ((rc = run_describe(c, st, nf))) return rc;
+        if ((rc = run_pack(c, st, nf, f0, n_frames, d_kp, kp_cap, d_desc, desc_cap, d_counts, c->d_stats))) return rc;
+        c->last_sub_frames = nf;
+    }
+    if (d_totals) HIP_TRY(hipMemcpyAsync(d_totals, c->d_state, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return SIFTMI_OK;
+}
+
 extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_frames, const void *d_pixels, int format, size_t row_stride,
                                                    size_t frame_stride, siftmi_keypoint *d_keypoints, int64_t kp_capacity,
                                                    siftmi_descriptor *d_descriptors, int64_t desc_capacity, int32_t *d_counts,
@@ -466,19 +498,41 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     rc = ensure_stats(c, n_frames);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
-    for (int f0 = 0; f0 < n_frames; f0 += c->B) {
-        const int nf = std::min(c->B, n_frames - f0);
-        const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
-        if ((rc = run_dense(c, st, nf, px, format, row_stride, frame_stride))) return rc;
-        if ((rc = run_detect(c, st, nf))) return rc;
-        if ((rc = run_describe(c, st, nf))) return rc;
-        if ((rc = run_pack(c, st, nf, f0, n_frames, (KeypointRec *)d_keypoints, kp_capacity, (DescriptorRec *)d_descriptors, desc_capacity,
-                           d_counts, c->d_stats)))
-            return rc;
-        c->last_sub_frames = nf;
+    const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && getenv("SIFTMI_NO_GRAPH") == nullptr;
+    if (want_graph) {
+        const siftmi_ctx::GraphKey key{d_pixels, n_frames, format, row_stride, frame_stride, d_keypoints, (long long)kp_capacity, d_descriptors,
+                                       (long long)desc_capacity, d_counts, d_totals, st};
+        if (!(c->gexec && key == c->gkey)) {
+            if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
+                                   (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals);
+                e = hipStreamEndCapture(st, &graph);
+                if (rc == SIFTMI_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+                else if (rc == SIFTMI_OK && e == hipSuccess) e = hipErrorUnknown;
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (rc != SIFTMI_OK || e != hipSuccess || !c->gexec) {
+                (void)hipGetLastError();
+                c->gexec = nullptr;
+                c->graph_failed = true;          // fall through to direct launches, now and later
+            } else {
+                c->gkey = key;
+            }
+        }
+        if (c->gexec) {
+            HIP_TRY(hipGraphLaunch(c->gexec, st));
+            c->last_sub_frames = std::min(c->B, n_frames - ((n_frames - 1) / c->B) * c->B);
+            c->last_frames = n_frames;
+            c->pyramid_valid = true;
+            return SIFTMI_OK;
+        }
     }
-    if (d_totals) HIP_TRY(hipMemcpyAsync(d_totals, c->d_state, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
+                       (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals);
+    if (rc) return rc;
     c->last_frames = n_frames;
     c->pyramid_valid = true;
     return SIFTMI_OK;

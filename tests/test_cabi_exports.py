@@ -48,7 +48,7 @@ def test_defaults_are_the_reference_literals(lib):
     assert abs(cfg.dog_threshold - 0.0133) < 1e-9 and cfg.edge_threshold == 10.0 and abs(cfg.max_offset - 0.6) < 1e-7
     assert cfg.lambda_orientation == 1.5 and abs(cfg.orientation_threshold - 0.8) < 1e-7 and cfg.orientation_smoothing == 6
     assert abs(cfg.sigma_min - 0.8) < 1e-7 and cfg.delta_min == 0.5 and cfg.sigma_in == 0.5
-    assert cfg.descriptor_scales_per_octave == 3 and cfg.full_neighbourhood == 0 and cfg.max_batch == 1
+    assert cfg.descriptor_scales_per_octave == 3 and cfg.full_neighbourhood == 0 and cfg.max_batch == 1 and cfg.use_hip_graph == 1
 
 
 def test_descriptor_record_conversion(lib):
