@@ -29,10 +29,13 @@ def _split(arr, counts):
 
 
 CASES = [
-    ("butterfly", None, 7),                 # the reference's own test image, its default 7 octaves
-    ("blob640", (640, 480), 3),             # BASELINE configs[0]
-    ("odd", (157, 93), 3),                  # widths not multiples of 4 -> scalar load/store path
-    ("tiny", (40, 36), 2),
+    ("butterfly", None, 7, 3),              # the reference's own test image, its default 7 octaves
+    ("blob640", (640, 480), 3, 3),          # BASELINE configs[0]
+    ("odd", (157, 93), 3, 3),               # widths not multiples of 4 -> scalar load/store path
+    ("tiny", (40, 36), 2, 3),
+    ("nspo4", (256, 192), 3, 4),            # other scales-per-octave: different tap counts / layer counts
+    ("nspo5", (200, 150), 2, 5),
+    ("tall", (130, 700), 4, 3),             # marching kernel: several steps per strip, ragged last step
 ]
 
 
@@ -44,12 +47,13 @@ def _image(name, size, butterfly_bgra):
     return blob_frame(size[0], size[1], 1)
 
 
-@pytest.mark.parametrize("name,size,no", CASES)
-def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no):
+@pytest.mark.parametrize("name,size,no,nspo", CASES)
+def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no, nspo):
     img = _image(name, size, butterfly_bgra)
     h, w = img.shape[:2]
-    eng = sm.Engine(w, h, n_octaves=no, keep_descriptor_floats=1)
-    orc = _oracle(w, h, no)
+    eng = sm.Engine(w, h, n_octaves=no, nspo=nspo, keep_descriptor_floats=1)
+    orc = _oracle(w, h, no, nspo=nspo)
+    NG = nspo + 3
     ref = orc.run(img, want_float=True)
 
     kps, kc, ds, dc = eng.detect_describe_batch(img[None])
@@ -59,15 +63,15 @@ def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no):
     # schedule
     for o in range(no):
         assert eng.octave_size(o)[:2] == orc.octave_size(o) and eng.octave_size(o)[2] == orc.delta(o)
-        for s in range(6):
+        for s in range(NG):
             assert eng.sigma(o, s) == orc.sigma(o, s)
-    for l in range(6):
+    for l in range(NG):
         assert np.array_equal(eng.weights(l), orc.weights(l))
 
     tot_kp = tot_match = 0
     for o in range(no):
         # 1. Gaussian stack: bit-exact
-        for s in range(6):
+        for s in range(NG):
             G, R = eng.gaussian(o, s), orc.gaussian(o, s)
             assert np.array_equal(G, R), "octave %d layer %d: max |d| = %g" % (o, s, np.abs(G - R).max())
         # 2. extrema: identical raw count, identical candidate set
@@ -204,6 +208,9 @@ def test_errors_and_capacity(sm):
     with pytest.raises(sm.SiftmiError) as e:
         sm.Engine(64, 64, device=99)
     assert e.value.code == _capi.E_BADARG
+    with pytest.raises(sm.SiftmiError) as e:
+        sm.Engine(256, 192, n_octaves=3, nspo=2)            # layer 4 would need 37 taps; the reference's
+    assert e.value.code == _capi.E_BADARG and "taps" in str(e.value)   # ConvolutionParameters holds 32 (ConvolutionSeries.h:13)
     img = blob_frame(320, 240, 0)
     eng = sm.Engine(320, 240, n_octaves=3, max_keypoints=16, max_descriptors=16)
     with pytest.raises(sm.SiftmiError) as e:
@@ -281,3 +288,31 @@ def test_device_resident_batch_graph_replay_matches_host_api(sm):
     torch.cuda.synchronize()
     r2 = fs2.results_host()
     assert np.array_equal(r2["keypoints"], want[0]) and np.array_equal(r2["descriptors"], want[2])
+
+
+def test_large_single_tile_4096_6_octaves(sm):
+    """BASELINE configs[4] shape (one large aerial tile, 6 octaves) at 4096x4096: pyramid bit-exact on a
+    deep layer of every octave, raw extrema counts equal, keypoint sets agree; plus an 8192x8192 GPU-only
+    run (36 GB of stacks) checked through size-independent properties."""
+    img = blob_frame(4096, 4096, 11, n_blobs=20000, gray=True)
+    eng = sm.Engine(4096, 4096, n_octaves=6)
+    k, kc, d, dc = eng.detect_describe_batch(img[None])
+    orc = _oracle(4096, 4096, 6)
+    ref = orc.run(img)
+    got = _split(k, kc[0])
+    tot = match = 0
+    for o in range(6):
+        assert np.array_equal(eng.gaussian(o, 5), orc.gaussian(o, 5)) and np.array_equal(eng.gaussian(o, 3), orc.gaussian(o, 3))
+        assert eng.stats()["raw_extrema"][0, o] == len(ref[o]["extrema"])
+        rep, _ = parity.compare_keypoints(got[o], ref[o]["keypoints"])
+        tot += max(rep["n_gpu"], rep["n_ref"]); match += rep["matched"]
+    assert match >= 0.995 * tot and tot > 5000
+    assert abs(int(dc.sum()) - sum(len(r["descriptors"]) for r in ref)) <= max(3, int(dc.sum()) // 200)
+    del eng, orc, ref
+    big = np.tile(img, (2, 2))                       # 8192 x 8192: the 4096 tile mirrored into a 2x2 mosaic
+    e8 = sm.Engine(8192, 8192, n_octaves=6)
+    k8, kc8, d8, dc8 = e8.detect_describe_batch(big[None])
+    k8b, kc8b, d8b, dc8b = e8.detect_describe_batch(big[None])
+    assert np.array_equal(k8, k8b) and np.array_equal(d8, d8b)          # deterministic
+    assert 3.5 * kc[0].sum() < kc8[0].sum() < 4.5 * kc[0].sum()         # ~4x the content
+    assert (np.diff(k8["octave"]) >= 0).all()
