@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "8")), help="frames processed in lock-step per launch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "32")), help="frames processed in lock-step per launch")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (cycled to fill the batch)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
