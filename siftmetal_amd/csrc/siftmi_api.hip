@@ -312,15 +312,21 @@ static void t_collect(siftmi_ctx *c) {
 template <int R, bool SEED>
 static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
                                 const TapWeights &wt, const SeedSource &seed) {
+    bool march = false;
     if constexpr (!SEED && R >= 12) {
-        // widest kernels: marching form (no vertical-halo recompute), measured faster from 25 taps up
+        // widest kernels on large launches: marching form (no vertical-halo recompute), measured faster from
+        // 25 taps up when there are enough strips x chunks to fill the chip (octaves 0-1 of a 1080p batch)
         using Gm = MarchGeom<R>;
         const int spc = 4;
         const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + spc * Gm::S - 1) / (spc * Gm::S)) * nf;
-        dim3 grid(((total + 7) / 8) * 8, 1, 1);
-        hipLaunchKernelGGL((blur_march_kernel<R, 1>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
-                           c->frame_stride, wt, nf, spc);
-    } else {
+        if (total >= 4000) {
+            march = true;
+            dim3 grid(((total + 7) / 8) * 8, 1, 1);
+            hipLaunchKernelGGL((blur_march_kernel<R, 1>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
+                               c->frame_stride, wt, nf, spc);
+        }
+    }
+    if (!march) {
         using S = BlurShip<R>;
         using Gm = typename S::G;
         const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + Gm::TH - 1) / Gm::TH) * nf;
