@@ -313,16 +313,18 @@ template <int R, bool SEED>
 static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
                                 const TapWeights &wt, const SeedSource &seed) {
     bool march = false;
-    if constexpr (!SEED && R >= 12) {
-        // widest kernels on large launches: marching form (no vertical-halo recompute), measured faster from
-        // 25 taps up when there are enough strips x chunks to fill the chip (octaves 0-1 of a 1080p batch)
-        using Gm = MarchGeom<R>;
-        const int spc = 4;
+    if constexpr (!SEED) {
+        // large launches: marching form (no vertical-halo recompute, next rows prefetched under the FMA phases);
+        // 12-29 % faster than the tile form at every radius on 32 x 3840x2160 (tools/ubench/blur_variants.hip),
+        // but it needs enough strips x chunks to fill the chip, so small octaves keep the tile kernel.
+        constexpr int S = 16;
+        using Gm = MarchGeom<R, S>;
+        const int spc = 8;
         const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + spc * Gm::S - 1) / (spc * Gm::S)) * nf;
-        if (total >= 4000) {
+        if (total >= 2000) {
             march = true;
             dim3 grid(((total + 7) / 8) * 8, 1, 1);
-            hipLaunchKernelGGL((blur_march_kernel<R, 1>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
+            hipLaunchKernelGGL((blur_march_kernel<R, 4, S>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
                                c->frame_stride, wt, nf, spc);
         }
     }

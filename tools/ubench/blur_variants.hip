@@ -79,16 +79,11 @@ static void bench_R(Ctx &c, float rho) {
         dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("v2x TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf); }); }
     V2X(32, 256, 4, 1, 0)
-#define VM(SPC_, MINW_) { using G = MarchGeom<R>; \
+#define VM(SPC_, MINW_, S_) { using G = MarchGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_); }); }
-    VM(4, 1)
-#define VS(NTHR_, RPC_, MINW_) { using G = StreamGeom<R, NTHR_>; \
-        const int ns = (c.w + G::SW - 1) / G::SW, nch = (c.h + RPC_ - 1) / RPC_; \
-        dim3 grid(ns * nch * c.nf, 1, 1); \
-        run_variant("stream thr=" #NTHR_ " rows/chunk=" #RPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_stream_kernel<R, NTHR_, MINW_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, RPC_); }); }
-    VS(256, 135, 1) VS(256, 270, 1) VS(256, 540, 1) VS(128, 135, 1) VS(128, 270, 1) VS(128, 540, 1) VS(64, 270, 1)
+        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_); }); }
+    VM(2, 1, 32) VM(4, 1, 32) VM(8, 1, 32) VM(4, 1, 16) VM(8, 1, 16) VM(16, 1, 16) VM(8, 4, 16) VM(4, 1, 64)
 }
 
 int main(int argc, char **argv) {
