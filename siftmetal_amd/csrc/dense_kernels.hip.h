@@ -46,6 +46,15 @@ __device__ __forceinline__ int symm(int i, int l) {
     return i;
 }
 
+// Optional second output of a layer blur: the next octave's layer 0 = even rows / even columns of this
+// layer (NearestNeighborDownScale.metal:15-22, DifferenceOfGaussians.swift:193-199), written by the lanes that
+// hold those pixels so that the decimation costs no extra launch and no re-read.
+struct Decimate {
+    float *dst;                     // next octave layer 0, frame 0 (nullptr = off)
+    size_t frame_stride;            // floats between frames
+    int w2, h2;                     // next octave size
+};
+
 struct SeedSource {                 // input frame description for the seed loader
     const unsigned char *pixels;    // frame 0
     size_t frame_stride;            // bytes between frames
@@ -118,9 +127,10 @@ struct Blur2Geom {
     static_assert(TH % RB == 0, "TH must be a multiple of RB");
 };
 
-template <int R, int TH_, int NTHR_, int HO_, int RB_, bool SEED, int MINW = 1, int KCH = 0, bool XCD = false>
+template <int R, int TH_, int NTHR_, int HO_, int RB_, bool SEED, int MINW = 1, int KCH = 0, bool XCD = false, bool DEC = false>
 __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
-                                                           size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt, SeedSource seed, int n_frames) {
+                                                           size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt, SeedSource seed, int n_frames,
+                                                           Decimate dec) {
     using G = Blur2Geom<R, TH_, NTHR_, HO_, RB_>;
     constexpr int NTHR = G::NTHR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -258,6 +268,11 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
                 if (gx + 2 < w) o[2] = acc[rr].z;
                 if (gx + 3 < w) o[3] = acc[rr].w;
             }
+            if (DEC && (gy & 1) == 0 && (gy >> 1) < dec.h2) {          // gx is a multiple of 4: columns gx, gx+2 are even
+                float *o2 = dec.dst + (size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1);
+                if ((gx >> 1) + 0 < dec.w2 && gx + 0 < w) o2[0] = acc[rr].x;
+                if ((gx >> 1) + 1 < dec.w2 && gx + 2 < w) o2[1] = acc[rr].z;
+            }
         }
     }
 }
@@ -281,10 +296,10 @@ struct MarchGeom {
     static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
 };
 
-template <int R, int MINW = 1, int S_ = 32>
+template <int R, int MINW = 1, int S_ = 32, bool DEC = false>
 __global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
-                                                              int n_frames, int spc /* steps per chunk */) {
+                                                              int n_frames, int spc /* steps per chunk */, Decimate dec) {
     using G = MarchGeom<R, S_>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -409,6 +424,11 @@ __global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__re
                     if (gx + 1 < w) o[1] = acc[rr].y;
                     if (gx + 2 < w) o[2] = acc[rr].z;
                     if (gx + 3 < w) o[3] = acc[rr].w;
+                }
+                if (DEC && (gy & 1) == 0 && (gy >> 1) < dec.h2) {
+                    float *o2 = dec.dst + (size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1);
+                    if ((gx >> 1) + 0 < dec.w2 && gx + 0 < w) o2[0] = acc[rr].x;
+                    if ((gx >> 1) + 1 < dec.w2 && gx + 2 < w) o2[1] = acc[rr].z;
                 }
             }
         }

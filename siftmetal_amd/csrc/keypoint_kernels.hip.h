@@ -557,10 +557,15 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
     // take neighbouring samples, which mostly fall into the same cell and bin, and same-address lanes
     // of one ds_add_u64 serialise (6 cycles distinct, 26 at 4 lanes per address).  u64 fixed point: see to_fix40.
     constexpr int NCOPY = 8;
+    constexpr int MAXCOL = 192;                            // window columns handled by the compacted walk (3 per lane)
     __shared__ unsigned long long patch_all[4][NCOPY][DESC_N];
+    __shared__ int col_start_all[4][MAXCOL + 1];
+    __shared__ short col_lo_all[4][MAXCOL];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long *patch = patch_all[wv][lane & (NCOPY - 1)];
     unsigned long long *patch0 = patch_all[wv][0];
+    int *col_start = col_start_all[wv];
+    short *col_lo = col_lo_all[wv];
     const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(desc_count[group], P.cap_desc[o]);
     const int w = P.w[o], h = P.h[o];
@@ -588,21 +593,69 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
 
 #pragma unroll
         for (int c = 0; c < NCOPY * DESC_N / 64; c++) patch0[c * 64 + lane] = 0ull;   // all copies (contiguous)
+        const int side = 2 * radius + 1;
+
+        // The reference visits every (j, i) of the (2 radius + 1)^2 window (metal :194-195), but a sample adds
+        // something only if its cell coordinates fall inside (-1, 4)^2, i.e. inside a rotated square of half
+        // width 2.5 histogramWidth -- about half the window.  Per window column j the i's that can qualify form
+        // one interval; compute a conservative interval per column (+-2 px of float slack), prefix-sum the
+        // lengths and walk the compacted index space, so that all 64 lanes hold candidate samples.  The exact
+        // per-sample test below is unchanged, hence exactly the same samples contribute.
+        const bool compact = side <= MAXCOL;
+        int total;
+        if (compact) {
+            const float Lh = 2.5f * histogramWidth;
+            int run = 0;
+            for (int c0 = 0; c0 < side; c0 += 64) {
+                const int cidx = c0 + lane;
+                int lo = 1, hi = 0;
+                if (cidx < side) {
+                    const float jf = (float)(cidx - radius);
+                    // |jf*cosT - i*sinT| < Lh  and  |jf*sinT + i*cosT| < Lh
+                    float a0 = -(float)radius, a1 = (float)radius;
+                    if (fabsf(sinT) > 1e-6f) {
+                        const float u = (jf * cosT - Lh) / sinT, v = (jf * cosT + Lh) / sinT;
+                        a0 = fmaxf(a0, fminf(u, v)); a1 = fminf(a1, fmaxf(u, v));
+                    } else if (fabsf(jf * cosT) >= Lh + 1.0f) { a1 = a0 - 1.0f; }
+                    if (fabsf(cosT) > 1e-6f) {
+                        const float u = (-Lh - jf * sinT) / cosT, v = (Lh - jf * sinT) / cosT;
+                        a0 = fmaxf(a0, fminf(u, v)); a1 = fminf(a1, fmaxf(u, v));
+                    } else if (fabsf(jf * sinT) >= Lh + 1.0f) { a1 = a0 - 1.0f; }
+                    lo = max(-radius, (int)floorf(a0) - 2);
+                    hi = min(radius, (int)ceilf(a1) + 2);
+                }
+                const int len = max(hi - lo + 1, 0);
+                int incl = len;                                            // inclusive wave prefix sum
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                if (cidx < side) { col_start[cidx] = run + incl - len; col_lo[cidx] = (short)lo; }
+                run += __shfl(incl, 63);
+            }
+            total = run;
+            if (lane == 0) col_start[side] = total;
+        } else {
+            total = side * side;
+        }
         __builtin_amdgcn_wave_barrier();
-        const int side = 2 * radius + 1, total = side * side;
-        // sample idx -> (j = idx / side - radius, i = idx % side - radius), advanced incrementally
-        int jj = lane / side, ii = lane - jj * side;
-        const int dj = 64 / side, di_ = 64 - dj * side;
+        __threadfence_block();
+
         for (int idx = lane; idx < total; idx += 64) {
-            const int j = jj - radius, i = ii - radius;                   // j: x offset (outer), i: y offset (inner)
-            ii += di_; jj += dj;
-            if (ii >= side) { ii -= side; jj += 1; }
+            int j, i;                                                      // j: x offset (outer), i: y offset (inner)
+            if (compact) {
+                int lo_c = 0, hi_c = side - 1;                             // last column whose start <= idx
+                while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= idx) lo_c = mid; else hi_c = mid - 1; }
+                j = lo_c - radius;
+                i = (int)col_lo[lo_c] + (idx - col_start[lo_c]);
+            } else {
+                const int jj = idx / side;
+                j = jj - radius; i = idx - jj * side - radius;
+            }
             const float rx = ((float)j * cosT - (float)i * sinT) / histogramWidth;
             const float ry = ((float)j * sinT + (float)i * cosT) / histogramWidth;
             const float bx = rx + (float)(d / 2) - 0.5f;
             const float by = ry + (float)(d / 2) - 0.5f;
             // every trilinear corner of this sample lies outside the 4x4 grid (addValue :66-68 drops
-            // all 8 contributions): nothing to add, skip the gradient entirely
+            // all 8 contributions): nothing to add
             if (bx <= -1.0f || bx >= 4.0f || by <= -1.0f || by >= 4.0f) continue;
             const float fx = truncf(px + (float)j), fy = truncf(py + (float)i);   // ushort2(px + j, py + i)
             float gth = 0.0f, gm = 0.0f;

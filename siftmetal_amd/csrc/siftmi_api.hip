@@ -309,9 +309,9 @@ static void t_collect(siftmi_ctx *c) {
 
 // ------------------------------------------------------------------------------------------------
 // launches
-template <int R, bool SEED>
-static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
-                                const TapWeights &wt, const SeedSource &seed) {
+template <int R, bool SEED, bool DEC>
+static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
+                                 const TapWeights &wt, const SeedSource &seed, const Decimate &dec) {
     bool march = false;
     if constexpr (!SEED) {
         // large launches: marching form (no vertical-halo recompute, next rows prefetched under the FMA phases);
@@ -324,8 +324,8 @@ static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src,
         if (total >= 2000) {
             march = true;
             dim3 grid(((total + 7) / 8) * 8, 1, 1);
-            hipLaunchKernelGGL((blur_march_kernel<R, 4, S>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
-                               c->frame_stride, wt, nf, spc);
+            hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
+                               c->frame_stride, wt, nf, spc, dec);
         }
     }
     if (!march) {
@@ -333,17 +333,26 @@ static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src,
         using Gm = typename S::G;
         const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + Gm::TH - 1) / Gm::TH) * nf;
         dim3 grid(((total + 7) / 8) * 8, 1, 1);          // XCD-aware 1-D tile order, see blur2_kernel
-        hipLaunchKernelGGL((blur2_kernel<R, S::TH, S::NTHR, 4, S::RB, SEED, 1, 0, true>), grid, dim3(S::NTHR),
-                           SEED ? Gm::seed_lds_bytes : Gm::lds_bytes, st, src, dst, w, h, c->frame_stride, c->frame_stride, wt, seed, nf);
+        hipLaunchKernelGGL((blur2_kernel<R, S::TH, S::NTHR, 4, S::RB, SEED, 1, 0, true, DEC>), grid, dim3(S::NTHR),
+                           SEED ? Gm::seed_lds_bytes : Gm::lds_bytes, st, src, dst, w, h, c->frame_stride, c->frame_stride, wt, seed, nf, dec);
     }
     return hipGetLastError();
 }
 
+template <int R, bool SEED>
+static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
+                                const TapWeights &wt, const SeedSource &seed, const Decimate &dec) {
+    if constexpr (!SEED) {
+        if (dec.dst) return launch_blur_rd<R, SEED, true>(c, st, src, dst, w, h, nf, wt, seed, dec);
+    }
+    return launch_blur_rd<R, SEED, false>(c, st, src, dst, w, h, nf, wt, seed, dec);
+}
+
 template <bool SEED>
 static hipError_t launch_blur(siftmi_ctx *c, hipStream_t st, int radius, const float *src, float *dst, int w, int h, int nf,
-                              const TapWeights &wt, const SeedSource &seed) {
+                              const TapWeights &wt, const SeedSource &seed, const Decimate &dec) {
     switch (radius) {
-#define CASE_R(r) case r: return launch_blur_r<r, SEED>(c, st, src, dst, w, h, nf, wt, seed);
+#define CASE_R(r) case r: return launch_blur_r<r, SEED>(c, st, src, dst, w, h, nf, wt, seed, dec);
         CASE_R(1) CASE_R(2) CASE_R(3) CASE_R(4) CASE_R(5) CASE_R(6) CASE_R(7) CASE_R(8)
         CASE_R(9) CASE_R(10) CASE_R(11) CASE_R(12) CASE_R(13) CASE_R(14) CASE_R(15)
 #undef CASE_R
@@ -362,22 +371,20 @@ static int run_dense(siftmi_ctx *c, hipStream_t st, int nf, const void *d_pixels
     seed.pixels = (const unsigned char *)d_pixels; seed.frame_stride = frame_stride; seed.row_stride = row_stride;
     seed.format = format; seed.in_w = c->cfg.width; seed.in_h = c->cfg.height;
     SeedSource none; memset(&none, 0, sizeof(none));
+    Decimate nodec; memset(&nodec, 0, sizeof(nodec));
     t_begin(c, SIFTMI_T_SEED);
-    HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed)));
+    HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed, nodec)));
     t_end(c);
     for (int o = 0; o < c->n_oct; o++) {
-        if (o > 0) {
-            t_begin(c, SIFTMI_T_DOWNSAMPLE);
-            dim3 grid((c->ow[o] + 63) / 64, (c->oh[o] + 3) / 4, nf);
-            hipLaunchKernelGGL(downsample_kernel, grid, dim3(256), 0, st, gauss_ptr(c, o - 1, c->nspo), gauss_ptr(c, o, 0),
-                               c->ow[o - 1], c->oh[o - 1], c->ow[o], c->oh[o], c->frame_stride, c->frame_stride);
-            HIP_TRY(hipGetLastError());
-            t_end(c);
-        }
         for (int s = 1; s < NG; s++) {
+            // the blur that produces layer nspo also emits the next octave's layer 0 (even pixels)
+            Decimate dec = nodec;
+            if (s == c->nspo && o + 1 < c->n_oct) {
+                dec.dst = gauss_ptr(c, o + 1, 0); dec.frame_stride = c->frame_stride; dec.w2 = c->ow[o + 1]; dec.h2 = c->oh[o + 1];
+            }
             t_begin(c, SIFTMI_T_BLUR);
             HIP_TRY((launch_blur<false>(c, st, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
-                                        nf, c->layer_w[s - 1], none)));
+                                        nf, c->layer_w[s - 1], none, dec)));
             t_end(c);
         }
     }
@@ -886,12 +893,13 @@ extern "C" int siftmi_time_blur(siftmi_ctx *c, int o, int layer, int iters, doub
         return set_error(SIFTMI_E_BADARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     SeedSource none; memset(&none, 0, sizeof(none));
+    Decimate nodec; memset(&nodec, 0, sizeof(nodec));
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, c->stream));
     for (int i = 0; i < iters; i++)
         HIP_TRY((launch_blur<false>(c, c->stream, (c->taps[layer - 1] - 1) / 2, gauss_ptr(c, o, layer - 1), gauss_ptr(c, o, layer), c->ow[o],
-                                    c->oh[o], c->B, c->layer_w[layer - 1], none)));
+                                    c->oh[o], c->B, c->layer_w[layer - 1], none, nodec)));
     HIP_TRY(hipEventRecord(b, c->stream));
     HIP_TRY(hipEventSynchronize(b));
     float ms = 0.0f;

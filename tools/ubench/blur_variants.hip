@@ -70,19 +70,19 @@ static void bench_R(Ctx &c, float rho) {
     hipLaunchKernelGGL(naive_x, g, dim3(256), 0, 0, c.src, c.tmp, c.w, c.h, wt, n);
     hipLaunchKernelGGL(naive_y, g, dim3(256), 0, 0, c.tmp, c.ref, c.w, c.h, wt, n);
     CHECK(hipDeviceSynchronize());
-    SeedSource none; memset(&none, 0, sizeof(none));
+    SeedSource none; memset(&none, 0, sizeof(none)); Decimate nodec; memset(&nodec, 0, sizeof(nodec));
 #define V2(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
         dim3 grid((c.w + G::TW - 1) / G::TW, (c.h + G::TH - 1) / G::TH, c.nf); \
-        run_variant("v2 TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " kch=" #KCH_, c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf); }); }
+        run_variant("v2 TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " kch=" #KCH_, c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec); }); }
 #define V2X(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
         const int total = ((c.w + G::TW - 1) / G::TW) * ((c.h + G::TH - 1) / G::TH) * c.nf; \
         dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("v2x TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf); }); }
+        run_variant("v2x TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec); }); }
     V2X(32, 256, 4, 1, 0)
 #define VM(SPC_, MINW_, S_) { using G = MarchGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_); }); }
+        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
     VM(2, 1, 32) VM(4, 1, 32) VM(8, 1, 32) VM(4, 1, 16) VM(8, 1, 16) VM(16, 1, 16) VM(8, 4, 16) VM(4, 1, 64)
 }
 
