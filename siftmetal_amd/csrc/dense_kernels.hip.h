@@ -296,7 +296,7 @@ struct MarchGeom {
     static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
 };
 
-template <int R, int MINW = 1, int S_ = 32, bool DEC = false>
+template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */>
 __global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                               int n_frames, int spc /* steps per chunk */, Decimate dec) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__re
         const bool has_next = (st + 1 < spc) && (y0 + G::S < h);
         // the S new input rows of the next step are image rows y0+S+R ... y0+2S+R-1
         const bool pf_ok = has_next && plain(y0 + G::S + R, G::S);          // uniform
-        __syncthreads();                                     // B1: window rows are in LDS
+        if (!NOBAR) __syncthreads();                         // B1: window rows are in LDS
 
         // prefetch them into registers: the loads complete under the two FMA phases below
         f32x4 pf[G::NPF];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__re
             }
             *reinterpret_cast<float4 *>(rowp + G::RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        __syncthreads();                                     // B2: blurred rows complete
+        if (!NOBAR) __syncthreads();                         // B2: blurred rows complete
 
         // vertical pass: 4 columns x RB rows per lane, taps in increasing order
         {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__re
             const int idx = tid + j * G::NTHR;
             if (idx < 2 * R * 32) cr[j] = *reinterpret_cast<const f32x4 *>(lds + (G::S + (idx >> 5)) * G::LW + G::RP + (idx & 31) * 4);
         }
-        __syncthreads();                                     // B3: every read of this window is done
+        if (!NOBAR) __syncthreads();                         // B3: every read of this window is done
 #pragma unroll
         for (int j = 0; j < G::NCARRY; j++) {
             const int idx = tid + j * G::NTHR;

@@ -32,7 +32,7 @@ def collect(d, name):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name: continue
             k = r["Kernel_Name"]
-            if "blur2_kernel" not in k and "blur_march_kernel" not in k: continue
+            if "blur_march_kernel" not in k: continue        # the octave-0 launches of tools/prof_blur.py use the marching kernel
             vals[(k.split("(")[0][-60:], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return vals
 fetch, write = collect("fetch", "FETCH_SIZE"), collect("write", "WRITE_SIZE")
@@ -49,7 +49,7 @@ for key in sorted(fetch, key=lambda k: -k[1]):
     hbm = 2 * fm * 1024 + wm * 1024
     res.append({"kernel": kname, "grid": grid, "launches_sampled": len(f), "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm,
                 "hbm_bytes_per_launch_corrected": hbm})
-res = [r for r in res if r["grid"] == max(x["grid"] for x in res if x["kernel"] == r["kernel"])]
+res = [r for r in res if r["grid"] == max(x["grid"] for x in res)]     # octave-0 launches only
 json.dump({"workload": "octave 0 (3840x2160), 8 frames per launch", "algorithmic_bytes_per_launch": alg, "kernels": res,
            "correction": "hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"},
           open(out + "/blur_hbm_traffic_$TAG.json", "w"), indent=1)

@@ -83,7 +83,12 @@ static void bench_R(Ctx &c, float rho) {
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
-    VM(2, 1, 32) VM(4, 1, 32) VM(8, 1, 32) VM(4, 1, 16) VM(8, 1, 16) VM(16, 1, 16) VM(8, 4, 16) VM(4, 1, 64)
+    VM(8, 4, 16)
+#define VMN(SPC_, MINW_, S_) { using G = MarchGeom<R, S_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("march NOBARRIER(timing only) S=" #S_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, true>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
+    VMN(8, 4, 16)
 }
 
 int main(int argc, char **argv) {
