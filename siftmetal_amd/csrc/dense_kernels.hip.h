@@ -175,6 +175,31 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
         __syncthreads();
         const int wi = seed.in_w, hi = seed.in_h;
         const float dx = (float)wi / (float)w, dy = (float)hi / (float)h;
+        if (interior && w == 2 * wi && h == 2 * hi) {
+            // interior tile of the 2x seed image: no mirror, and an (even, odd) column pair shares its lumas.
+            // BilinearUpScale.metal:56-59 is fx*(fy*c0 + (1-fy)*c1) + (1-fx)*(fy*c2 + (1-fy)*c3); with A(i) the
+            // vertical blend of input column i this is fx*A(ip) + (1-fx)*A(im), and fx = 0 on even columns, so
+            // the even output is A(im) exactly (0 * finite + 1 * A) and the odd one 0.5*A(ip) + 0.5*A(im).
+            for (int idx = tid; idx < G::LH * (G::LW / 2); idx += NTHR) {
+                const int ly = idx / (G::LW / 2), lp = idx - ly * (G::LW / 2);
+                const int gy = y0 - R + ly, gx = x0 - G::RP + 2 * lp;       // gx even
+                const float y = (float)gy * dy;
+                int jm = (int)y, jp = jm + 1;
+                if (jp >= hi) jp = 2 * hi - 1 - jp;
+                const float fy = y - floorf(y);
+                const int im = gx >> 1;
+                int ip = im + 1;
+                if (ip >= wi) ip = 2 * wi - 1 - ip;
+                const float *rm = lum + (jm - iy0) * G::LWI - ix0, *rp = lum + (jp - iy0) * G::LWI - ix0;
+                const float Am = fy * rp[im] + (1.0f - fy) * rm[im];
+                const float Ap = fy * rp[ip] + (1.0f - fy) * rm[ip];
+                const float fx1 = ((float)(gx + 1) * dx) - floorf((float)(gx + 1) * dx);   // 0.5
+                float2 o;
+                o.x = 0.0f * Ap + (1.0f - 0.0f) * Am;
+                o.y = fx1 * Ap + (1.0f - fx1) * Am;
+                *reinterpret_cast<float2 *>(lds + ly * G::LW + 2 * lp) = o;
+            }
+        } else
         for (int idx = tid; idx < G::LH * G::LW; idx += NTHR) {
             const int ly = idx / G::LW, lx = idx - ly * G::LW;
             const int sx = symm(x0 - G::RP + lx, w), sy = symm(y0 - R + ly, h);

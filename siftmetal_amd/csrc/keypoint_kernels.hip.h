@@ -556,8 +556,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
     // NCOPY private copies of the 4x4x8 histogram per wave (copy = lane % NCOPY): neighbouring lanes
     // take neighbouring samples, which mostly fall into the same cell and bin, and same-address lanes
     // of one ds_add_u64 serialise (6 cycles distinct, 26 at 4 lanes per address).  u64 fixed point: see to_fix40.
-    constexpr int NCOPY = 8;
-    constexpr int MAXCOL = 192;                            // window columns handled by the compacted walk (3 per lane)
+    constexpr int NCOPY = 4;
+    constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
     __shared__ unsigned long long patch_all[4][NCOPY][DESC_N];
     __shared__ int col_start_all[4][MAXCOL + 1];
     __shared__ short col_lo_all[4][MAXCOL];
