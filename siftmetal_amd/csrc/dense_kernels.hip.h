@@ -310,10 +310,10 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
 // (S+2R)/S = 1.8x at R = 13) and every input row is fetched once per strip; the next step's S input
 // rows are prefetched into registers while this step computes (loads overlap the FMA phases).
 // Same arithmetic, same tap order: bit-identical to blur2_kernel and to the oracle.
-template <int R, int S_ = 32>
+template <int R, int S_ = 32, int NTHR_ = 256>
 struct MarchGeom {
     static constexpr int RP = (R + 3) & ~3;
-    static constexpr int TW = 128, S = S_, NTHR = 256, RB = S_ / 8;
+    static constexpr int TW = 128, S = S_, NTHR = NTHR_, RB = S_ / (NTHR_ / 32);
     static constexpr int LW = TW + 2 * RP, LH = S + 2 * R, NT = 2 * R + 1;
     static constexpr int V = LW / 4;                                    // float4 per staged row
     static constexpr int NPF = (S * V + NTHR - 1) / NTHR;               // prefetch float4 per lane
@@ -321,11 +321,11 @@ struct MarchGeom {
     static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
 };
 
-template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */>
-__global__ __launch_bounds__(256, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */, int NTHR_ = 256>
+__global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                               int n_frames, int spc /* steps per chunk */, Decimate dec) {
-    using G = MarchGeom<R, S_>;
+    using G = MarchGeom<R, S_, NTHR_>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     // XCD-aware 1-D order (see blur2_kernel): frame, chunk, strip with the strip index fastest

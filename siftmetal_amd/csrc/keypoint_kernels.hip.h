@@ -104,14 +104,18 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
 
     // window rows as separate arrays so that rotating them is a renaming (3x unrolled loop), not 45 moves
     float ra[ND][3], rb[ND][3], rc[ND][3];
-    auto load_row = [&](int y, float (&row)[ND][3]) {
-        const float *p = g0 + (size_t)y * w + xc;
-        float gprev = p[0];
+    // loads are issued one row ahead of their use (raw Gaussian values wait in `pend` while the previous
+    // row is tested), which doubles the bytes in flight per wave of this bandwidth-bound kernel
+    float pend[ND + 1];
+    auto issue = [&](int y) {
+        const float *p = g0 + (size_t)min(y, h - 1) * w + xc;
+#pragma unroll
+        for (int l = 0; l <= ND; l++) pend[l] = p[(size_t)l * n];
+    };
+    auto finish = [&](float (&row)[ND][3]) {
 #pragma unroll
         for (int l = 0; l < ND; l++) {
-            const float gcur = p[(size_t)(l + 1) * n];
-            const float dv = gcur - gprev;
-            gprev = gcur;
+            const float dv = pend[l + 1] - pend[l];
             row[l][1] = dv;
             row[l][0] = __shfl_up(dv, 1);
             row[l][2] = __shfl_down(dv, 1);
@@ -163,13 +167,14 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
             }
         }
     };
-    load_row(ya - 1, ra);
-    load_row(ya, rb);
+    issue(ya - 1); finish(ra);
+    issue(ya); finish(rb);
+    issue(ya + 1);
     for (int y = ya; y < yb; y += 3) {
-        load_row(y + 1, rc);
+        finish(rc); issue(y + 2);
         test_row(y, ra, rb, rc);
-        if (y + 1 < yb) { load_row(y + 2, ra); test_row(y + 1, rb, rc, ra); }
-        if (y + 2 < yb) { load_row(y + 3, rb); test_row(y + 2, rc, ra, rb); }
+        if (y + 1 < yb) { finish(ra); issue(y + 3); test_row(y + 1, rb, rc, ra); }
+        if (y + 2 < yb) { finish(rb); issue(y + 4); test_row(y + 2, rc, ra, rb); }
     }
     __syncthreads();
     const int nloc = min(s_cand, STAGE);

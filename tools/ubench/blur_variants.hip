@@ -84,11 +84,11 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
     VM(8, 4, 16)
-#define VMN(SPC_, MINW_, S_) { using G = MarchGeom<R, S_>; \
+#define VM2(SPC_, MINW_, S_, NTHR_) { using G = MarchGeom<R, S_, NTHR_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march NOBARRIER(timing only) S=" #S_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, true>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
-    VMN(8, 4, 16)
+        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_ " thr=" #NTHR_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, false, NTHR_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
+    VM2(8, 1, 16, 128) VM2(8, 2, 16, 128) VM2(4, 1, 32, 128) VM2(8, 1, 8, 128) VM2(16, 1, 8, 256)
 }
 
 int main(int argc, char **argv) {
