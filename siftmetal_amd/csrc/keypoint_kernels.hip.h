@@ -644,13 +644,19 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
 
+        int cur = 0;                                                       // column of this lane's current sample
+        if (compact && lane < total) {                                     // binary search once, then only advance
+            int lo_c = 0, hi_c = side - 1;                                 // last column whose start <= lane
+            while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= lane) lo_c = mid; else hi_c = mid - 1; }
+            cur = lo_c;
+        }
+        int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
         for (int idx = lane; idx < total; idx += 64) {
             int j, i;                                                      // j: x offset (outer), i: y offset (inner)
             if (compact) {
-                int lo_c = 0, hi_c = side - 1;                             // last column whose start <= idx
-                while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= idx) lo_c = mid; else hi_c = mid - 1; }
-                j = lo_c - radius;
-                i = (int)col_lo[lo_c] + (idx - col_start[lo_c]);
+                while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty columns have equal starts
+                j = cur - radius;
+                i = (int)col_lo[cur] + (idx - cur_start);
             } else {
                 const int jj = idx / side;
                 j = jj - radius; i = idx - jj * side - radius;
