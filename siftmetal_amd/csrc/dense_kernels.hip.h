@@ -95,6 +95,15 @@ __device__ __forceinline__ float seed_sample(const unsigned char *frame, const S
     return fx * (fy * c0 + (1.0f - fy) * c1) + (1.0f - fx) * (fy * c2 + (1.0f - fy) * c3);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0), which
+// drains every outstanding global load and store at each barrier -- fatal for kernels that keep
+// prefetches in flight across phases (the marching blur lost its whole load/compute overlap to it).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Tap weights live in VGPRs.  Measured on MI355X (tools/ubench/ubench_valu.hip): v_fmac_f32 with an
 // SGPR multiplicand issues at HALF the rate of the all-VGPR form (57-67 vs 108-126 TFLOP/s), so
 // the kernarg weights are copied into vector registers once per wave; the asm keeps the compiler
@@ -310,22 +319,26 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
 // (S+2R)/S = 1.8x at R = 13) and every input row is fetched once per strip; the next step's S input
 // rows are prefetched into registers while this step computes (loads overlap the FMA phases).
 // Same arithmetic, same tap order: bit-identical to blur2_kernel and to the oracle.
-template <int R, int S_ = 32, int NTHR_ = 256>
+template <int R, int S_ = 32, int NTHR_ = 256, int TW_ = 128>
 struct MarchGeom {
     static constexpr int RP = (R + 3) & ~3;
-    static constexpr int TW = 128, S = S_, NTHR = NTHR_, RB = S_ / (NTHR_ / 32);
+    static constexpr int TW = TW_, S = S_, NTHR = NTHR_, RB = S_ / (NTHR_ / (TW_ / 4));
     static constexpr int LW = TW + 2 * RP, LH = S + 2 * R, NT = 2 * R + 1;
     static constexpr int V = LW / 4;                                    // float4 per staged row
     static constexpr int NPF = (S * V + NTHR - 1) / NTHR;               // prefetch float4 per lane
     static constexpr int NCARRY = (2 * R * (TW / 4) + NTHR - 1) / NTHR; // carried float4 per lane
+    static_assert(TW == 128 || TW == 256, "strip width");
     static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
 };
 
-template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */, int NTHR_ = 256>
+template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */, int NTHR_ = 256,
+          int ABL = 0 /* timing ablation: 1 = no FMAs, 2 = no LDS reads in the two passes (wrong results) */,
+          int TW_ = 128>
 __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                               int n_frames, int spc /* steps per chunk */, Decimate dec) {
-    using G = MarchGeom<R, S_, NTHR_>;
+    using G = MarchGeom<R, S_, NTHR_, TW_>;
+    constexpr int QW = G::TW / 4, QSH = (QW == 64 ? 6 : 5);     // float4 columns per row
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     // XCD-aware 1-D order (see blur2_kernel): frame, chunk, strip with the strip index fastest
@@ -367,52 +380,64 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
     }
     const VTaps<G::NT> tw(wt);
 
-    for (int st = 0; st < spc; st++) {
-        const int y0 = ybeg + st * G::S;                     // first output row of this step
-        if (y0 >= h) break;                                  // uniform
-        const bool has_next = (st + 1 < spc) && (y0 + G::S < h);
-        // the S new input rows of the next step are image rows y0+S+R ... y0+2S+R-1
-        const bool pf_ok = has_next && plain(y0 + G::S + R, G::S);          // uniform
-        if (!NOBAR) __syncthreads();                         // B1: window rows are in LDS
-
-        // prefetch them into registers: the loads complete under the two FMA phases below
-        f32x4 pf[G::NPF];
-        if (pf_ok) {
-            const float *base = in + (size_t)(y0 + G::S + R) * w + (x0 - G::RP);
+    // Register prefetch, two steps deep: the S new input rows of step t+2 (image rows y0+2S+R ...) are
+    // requested at the start of step t and written to LDS at the end of step t+1, so every load has two
+    // steps of FMA work to land (one step was not enough: the steady-state loop ran slower than the
+    // prologue-heavy short chunks, i.e. it was waiting on memory latency).
+    auto issue_rows = [&](int ystep, f32x4 (&buf)[G::NPF]) {           // rows of the step whose first output row is ystep
+        const float *base = in + (size_t)(ystep + R) * w + (x0 - G::RP);
 #pragma unroll
-            for (int j = 0; j < G::NPF; j++) {
-                const int idx = tid + j * G::NTHR;
-                const int ly = idx / G::V, lv = idx - ly * G::V;
-                if ((j + 1) * G::NTHR <= G::S * G::V || idx < G::S * G::V)
-                    pf[j] = *reinterpret_cast<const f32x4 *>(base + (size_t)ly * w + 4 * lv);
-            }
+        for (int j = 0; j < G::NPF; j++) {
+            const int idx = tid + j * G::NTHR;
+            const int ly = idx / G::V, lv = idx - ly * G::V;
+            if ((j + 1) * G::NTHR <= G::S * G::V || idx < G::S * G::V)
+                buf[j] = *reinterpret_cast<const f32x4 *>(base + (size_t)ly * w + 4 * lv);
         }
+    };
+    auto step_ok = [&](int st) { return st < spc && ybeg + st * G::S < h; };                      // step exists
+    auto step_plain = [&](int st) { return step_ok(st) && plain(ybeg + st * G::S + R, G::S); };   // ... and its new rows are plain
+    f32x4 pfA[G::NPF], pfB[G::NPF];
+    if (step_plain(1)) issue_rows(ybeg + G::S, pfB);         // consumed at the end of step 0
+
+    auto body = [&](int st, f32x4 (&pf_issue)[G::NPF], f32x4 (&pf)[G::NPF]) -> bool {
+        const int y0 = ybeg + st * G::S;                     // first output row of this step
+        const bool has_next = step_ok(st + 1);
+        const bool pf_ok = step_plain(st + 1);               // uniform; its rows were requested one step ago
+        if (!NOBAR) lds_barrier();                         // B1: window rows are in LDS
+        if (step_plain(st + 2)) issue_rows(ybeg + (st + 2) * G::S, pf_issue);
 
         // horizontal pass, in place (first step: all LH rows; later steps: only the S new rows)
 #pragma unroll 1
-        for (int item = (st == 0 ? 0 : 2 * R * 32) + tid; item < G::LH * 32; item += G::NTHR) {
-            const int row = item >> 5, c4 = (item & 31) * 4;
+        for (int item = (st == 0 ? 0 : 2 * R * QW) + tid; item < G::LH * QW; item += G::NTHR) {
+            const int row = item >> QSH, c4 = (item & (QW - 1)) * 4;
             float *rowp = lds + row * G::LW;
             float v[4 + 2 * G::RP];
             const lds_cv_f32x4 *rp4 = (const lds_cv_f32x4 *)(rowp + c4);
 #pragma unroll
             for (int m = 0; m < (4 + 2 * G::RP) / 4; m++) {
-                const f32x4 tv = rp4[m];
+                f32x4 tv;
+                if (ABL >= 2) { tv.x = tv.y = tv.z = tv.w = (float)(item + m); } else tv = rp4[m];
                 v[4 * m + 0] = tv.x; v[4 * m + 1] = tv.y; v[4 * m + 2] = tv.z; v[4 * m + 3] = tv.w;
             }
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (ABL == 1 || ABL == 3) {
+#pragma unroll
+                for (int j = 0; j < 4 + 2 * G::RP; j++) asm volatile("" ::"v"(v[j]));
+                acc[0] = v[0]; acc[1] = v[5]; acc[2] = v[9]; acc[3] = v[13];
+            } else {
 #pragma unroll
             for (int i = 0; i < G::NT; i++) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(G::RP - R) + k + i], acc[k]);
             }
+            }
             *reinterpret_cast<float4 *>(rowp + G::RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        if (!NOBAR) __syncthreads();                         // B2: blurred rows complete
+        if (!NOBAR) lds_barrier();                         // B2: blurred rows complete
 
         // vertical pass: 4 columns x RB rows per lane, taps in increasing order
         {
-            const int cg = tid & 31, rg = tid >> 5;
+            const int cg = tid & (QW - 1), rg = tid >> QSH;
             const float *colp = lds + (rg * G::RB) * G::LW + G::RP + cg * 4;
             float4 acc[G::RB];
 #pragma unroll
@@ -420,7 +445,9 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
 #pragma unroll
             for (int k = 0; k < G::RB + 2 * R; k++) {
                 if (k > 0 && (k & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // bound the load look-ahead (VGPRs)
-                const float4 v = *reinterpret_cast<const float4 *>(colp + k * G::LW);
+                float4 v;
+                if (ABL >= 2) v = make_float4((float)k, (float)tid, 1.0f, 2.0f); else v = *reinterpret_cast<const float4 *>(colp + k * G::LW);
+                if (ABL == 1 || ABL == 3) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); if (k < G::RB) acc[k] = v; continue; }
 #pragma unroll
                 for (int rr = 0; rr < G::RB; rr++) {
                     const int i = k - rr;
@@ -457,20 +484,20 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
                 }
             }
         }
-        if (!has_next) break;                                // uniform
+        if (!has_next) return false;                         // uniform
 
         // carry the last 2R blurred rows (window rows S ... S+2R-1, columns RP ... RP+TW-1) to the top
         f32x4 cr[G::NCARRY];
 #pragma unroll
         for (int j = 0; j < G::NCARRY; j++) {
             const int idx = tid + j * G::NTHR;
-            if (idx < 2 * R * 32) cr[j] = *reinterpret_cast<const f32x4 *>(lds + (G::S + (idx >> 5)) * G::LW + G::RP + (idx & 31) * 4);
+            if (idx < 2 * R * QW) cr[j] = *reinterpret_cast<const f32x4 *>(lds + (G::S + (idx >> QSH)) * G::LW + G::RP + (idx & (QW - 1)) * 4);
         }
-        if (!NOBAR) __syncthreads();                         // B3: every read of this window is done
+        if (!NOBAR) lds_barrier();                         // B3: every read of this window is done
 #pragma unroll
         for (int j = 0; j < G::NCARRY; j++) {
             const int idx = tid + j * G::NTHR;
-            if (idx < 2 * R * 32) *reinterpret_cast<f32x4 *>(lds + (idx >> 5) * G::LW + G::RP + (idx & 31) * 4) = cr[j];
+            if (idx < 2 * R * QW) *reinterpret_cast<f32x4 *>(lds + (idx >> QSH) * G::LW + G::RP + (idx & (QW - 1)) * 4) = cr[j];
         }
         if (pf_ok) {
 #pragma unroll
@@ -483,6 +510,13 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
         } else {
             stage_rows(y0 + G::S, 2 * R, G::LH);             // border step: mirror path, straight to LDS
         }
+        return true;
+    };
+    for (int st = 0; st < spc; st += 2) {                    // two bodies per trip: the buffers swap roles statically
+        if (!step_ok(st)) break;
+        if (!body(st, pfA, pfB)) break;
+        if (!step_ok(st + 1)) break;
+        if (!body(st + 1, pfB, pfA)) break;
     }
 }
 

@@ -84,11 +84,16 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
     VM(8, 4, 16)
-#define VM2(SPC_, MINW_, S_, NTHR_) { using G = MarchGeom<R, S_, NTHR_>; \
+#define VMX(SPC_, MINW_, S_, NTHR_, ABL_) { using G = MarchGeom<R, S_, NTHR_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_ " thr=" #NTHR_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, false, NTHR_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
-    VM2(8, 1, 16, 128) VM2(8, 2, 16, 128) VM2(4, 1, 32, 128) VM2(8, 1, 8, 128) VM2(16, 1, 8, 256)
+        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_ " thr=" #NTHR_ " ABL=" #ABL_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, false, NTHR_, ABL_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
+    VMX(8, 4, 16, 256, 0)
+#define VMW(SPC_, MINW_, S_, TW_, ABL_) { using G = MarchGeom<R, S_, 256, TW_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_ " TW=" #TW_ " ABL=" #ABL_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, false, 256, ABL_, TW_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
+    VMW(8, 1, 16, 256, 0) VMW(8, 3, 16, 256, 0) VMW(16, 3, 16, 256, 0) VMW(8, 3, 16, 256, 3) VMW(8, 2, 32, 256, 0) VMX(8, 4, 16, 256, 3)
 }
 
 int main(int argc, char **argv) {
