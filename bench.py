@@ -73,6 +73,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # Library chatter (e.g. RCCL's version banner at communicator init) must not reach stdout: the
+    # contract is ONE JSON line.  Point fd 1 at stderr for the run and restore it for the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -85,7 +91,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SIFTMI_FORCE_GATHER=1 exercises the RCCL exchange with a single rank (smoke test on a 1-GPU box)
+    force_gather = os.environ.get("SIFTMI_FORCE_GATHER") == "1" and "RANK" in os.environ
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -109,7 +117,7 @@ def main():
 
     def step():
         runner.run(d_frames)
-        if world > 1:
+        if world > 1 or force_gather:
             runner.all_gather()
 
     for _ in range(args.warmup):
@@ -180,11 +188,32 @@ def main():
                            "algorithmic_bytes_per_launch_avg": int(total_bytes / max(blur_n, 1)),
                            "octave0_GBps_by_layer": per_layer, "stage_ms_per_step": stage_ms,
                            "measured_in": "second identical pass of K steps, hipEvents around every launch on the launch stream"}
+    if rank == 0:
+        # BASELINE configs[1]: ONE 1920x1080 frame per call (lock-step batch 1, hipGraph replay), frame in HBM
+        e1 = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=1)
+        r1 = smstream.FrameStream(e1, 1, device=dev)
+        one = d_frames[:1].contiguous()
+        for _ in range(3):
+            r1.run(one)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = 30
+        for _ in range(n1):
+            r1.run(one)
+        torch.cuda.synchronize()
+        ms1 = (time.perf_counter() - t1) / n1 * 1e3
+        out["config"]["single_frame"] = {"workload": "BASELINE configs[1]: one 1920x1080 frame per call, 4 octaves", "ms_per_frame": round(ms1, 4),
+                                         "Mpixels_per_s": round(W * H / ms1 / 1e3, 1)}
+        log("single frame: %.3f ms (%.0f Mpixels/s)" % (ms1, W * H / ms1 / 1e3))
+        del r1, e1
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(frames_np)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_gather:
         dist.destroy_process_group()
 
 
