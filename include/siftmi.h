@@ -190,7 +190,7 @@ int siftmi_copy_descriptor_floats(siftmi_ctx *ctx, int frame, int octave, float 
 /* --- timing (replaces Utilities/Performance.swift measure(name:) signposts) -------------------
    Stage ids for siftmi_get_timings: accumulated GPU milliseconds and launch counts since the
    last siftmi_reset_timings, measured with hipEvents on the context's stream when enabled. */
-enum { SIFTMI_T_SEED = 0, SIFTMI_T_BLUR = 1, SIFTMI_T_DOWNSAMPLE = 2, SIFTMI_T_EXTREMA = 3,
+enum { SIFTMI_T_SEED = 0, SIFTMI_T_BLUR = 1, SIFTMI_T_DOWNSAMPLE = 2 /* always 0: fused into the layer-nspo blur */, SIFTMI_T_EXTREMA = 3,
        SIFTMI_T_REFINE = 4, SIFTMI_T_SORT = 5, SIFTMI_T_ORIENT = 6, SIFTMI_T_DESCRIBE = 7,
        SIFTMI_T_PACK = 8, SIFTMI_T_COUNT = 9 };
 int siftmi_enable_timings(siftmi_ctx *ctx, int enable);

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include "dense_kernels.hip.h"
+#include "experimental_stream_blur.hip.h"
 using namespace siftmi;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
