@@ -333,7 +333,7 @@ struct MarchGeom {
 
 template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */, int NTHR_ = 256,
           int ABL = 0 /* timing ablation: 1 = no FMAs, 2 = no LDS reads in the two passes (wrong results) */,
-          int TW_ = 128>
+          int TW_ = 128, int VSB = 4>
 __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                               int n_frames, int spc /* steps per chunk */, Decimate dec) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
             for (int rr = 0; rr < G::RB; rr++) acc[rr] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
             for (int k = 0; k < G::RB + 2 * R; k++) {
-                if (k > 0 && (k & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // bound the load look-ahead (VGPRs)
+                if (VSB > 0 && k > 0 && (k % (VSB > 0 ? VSB : 1)) == 0) __builtin_amdgcn_sched_barrier(0);   // optional bound on the read look-ahead
                 float4 v;
                 if (ABL >= 2) v = make_float4((float)k, (float)tid, 1.0f, 2.0f); else v = *reinterpret_cast<const float4 *>(colp + k * G::LW);
                 if (ABL == 1 || ABL == 3) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); if (k < G::RB) acc[k] = v; continue; }

@@ -316,3 +316,65 @@ def test_large_single_tile_4096_6_octaves(sm):
     assert np.array_equal(k8, k8b) and np.array_equal(d8, d8b)          # deterministic
     assert 3.5 * kc[0].sum() < kc8[0].sum() < 4.5 * kc[0].sum()         # ~4x the content
     assert (np.diff(k8["octave"]) >= 0).all()
+
+
+def _natural_1080p(butterfly_bgra):
+    """SURVEY.md 8d 'dense stress variant': the reference's test image mirror-tiled to 1920x1080."""
+    b = butterfly_bgra
+    row = np.concatenate([b, b[:, ::-1], b, b[:, ::-1]], axis=1)
+    full = np.concatenate([row, row[::-1], row, row[::-1]], axis=0)
+    return np.ascontiguousarray(full[:1080, :1920])
+
+
+def test_dense_natural_texture_1080p_vs_oracle(sm, butterfly_bgra):
+    """~23k raw extrema / ~15k keypoints / ~17k descriptors per frame: list capacities,
+    the marching blur on a real image, and parity at density."""
+    img = _natural_1080p(butterfly_bgra)
+    eng = sm.Engine(1920, 1080, n_octaves=4, keep_descriptor_floats=1)
+    k, kc, d, dc = eng.detect_describe_batch(img[None])
+    st = eng.stats()
+    orc = _oracle(1920, 1080, 4)
+    ref = orc.run(img)
+    assert st["raw_extrema"][0].tolist() == [len(r["extrema"]) for r in ref]
+    assert st["raw_extrema"][0, 0] > 15000 and int(kc.sum()) > 10000
+    got_k, got_d = _split(k, kc[0]), _split(d, dc[0])
+    tot = match = 0
+    for o in range(4):
+        assert np.array_equal(eng.gaussian(o, 4), orc.gaussian(o, 4))
+        assert parity.ext_set(eng.extrema(o)) == parity.ext_set(parity.prefilter_extrema(orc, o, ref[o]["extrema"]))
+        rep, _ = parity.compare_keypoints(got_k[o], ref[o]["keypoints"])
+        tot += max(rep["n_gpu"], rep["n_ref"]); match += rep["matched"]
+        assert rep["max_abs_px"] <= parity.TOL_ABS_PX and rep["max_value"] <= parity.TOL_VALUE
+        okp = parity.to_oracle_keypoints(got_k[o])
+        g_ori = eng.orientations(o)
+        orep = parity.compare_orientations(g_ori, orc.orientations(o, okp), len(okp))
+        assert orep["count_mismatch"] <= max(1, len(okp) // 200) and orep["max_dtheta"] <= parity.TOL_THETA, orep
+        in_ori = parity.to_oracle_orientations(g_ori)
+        r_desc, r_f32 = orc.descriptors(o, okp, in_ori, want_float=True)
+        drep = parity.compare_descriptors(got_d[o], eng.descriptor_floats(o), r_desc, r_f32, in_ori)
+        assert drep["max_bin_diff"] <= 1 and drep["frac_differing"] <= parity.MAX_DESC_BIN_FRAC and drep["max_l2_float"] <= parity.TOL_DESC_L2, drep
+    assert match >= 0.995 * tot, (match, tot)
+
+
+def test_heavy_noise_never_overruns(sm):
+    """Unstructured input (white noise) and a deliberately tiny candidate capacity.  Either everything
+    fits, or the call reports SIFTMI_E_CAPACITY with truncated-but-valid results -- never a crash."""
+    from siftmetal_amd import _capi
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (540, 960), dtype=np.uint8)
+    eng = sm.Engine(960, 540, n_octaves=4)
+    try:
+        k, kc, d, dc = eng.detect_describe_batch(img[None])
+    except sm.SiftmiError as e:
+        assert e.code == _capi.E_CAPACITY
+        k, kc, d, dc = eng.detect_describe_batch(img[None], allow_capacity=True)
+    st = eng.stats()
+    assert st["raw_extrema"][0, 0] > 500
+    assert len(k) == int(kc.sum()) and len(d) == int(dc.sum())
+    assert (k["x"] >= 5).all() and (k["scale"] >= 1).all() and (k["scale"] <= 3).all()
+    small = sm.Engine(960, 540, n_octaves=4, max_extrema=64)            # force the overflow path
+    with pytest.raises(sm.SiftmiError) as e:
+        small.detect_describe_batch(img[None])
+    assert e.value.code == _capi.E_CAPACITY and "extrema" in str(e.value)
+    k2, kc2, d2, dc2 = small.detect_describe_batch(img[None], allow_capacity=True)
+    assert small.stats()["candidates"][0, 0] > 64 and len(k2) <= len(k)

@@ -94,7 +94,11 @@ static void bench_R(Ctx &c, float rho) {
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_ " TW=" #TW_ " ABL=" #ABL_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, false, 256, ABL_, TW_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
-    VMW(8, 1, 16, 256, 0) VMW(8, 3, 16, 256, 0) VMW(16, 3, 16, 256, 0) VMW(8, 3, 16, 256, 3) VMW(8, 2, 32, 256, 0) VMX(8, 4, 16, 256, 3)
+#define VMS(MINW_, VSB_) { using G = MarchGeom<R, 16, 256, 128>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + 8 * G::S - 1) / (8 * G::S); \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("march S=16 spc=8 minw=" #MINW_ " vsb=" #VSB_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, 16, false, false, 256, 0, 128, VSB_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, 8, nodec); }); }
+    VMS(4, 0) VMS(4, 2) VMS(4, 8) VMS(3, 0)
 }
 
 int main(int argc, char **argv) {
