@@ -176,7 +176,8 @@ def main():
         prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("blur_hbm_traffic_")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
         if prof:
             pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-            ks = [k for k in pj["kernels"] if "blur_march_kernel" in k["kernel"] and k["kernel"].rstrip().endswith(", false, false>")]   # layer kernels without the fused decimation output
+            import re
+            ks = [k for k in pj["kernels"] if re.search(r"blur_march_kernel<\d+, \d+, \d+, false", k["kernel"])]   # layer kernels without the fused decimation output
             if ks:
                 ratio = sum(k["hbm_bytes_per_launch_corrected"] for k in ks) / (pj["algorithmic_bytes_per_launch"] * len(ks))
                 traffic = int(ratio * total_bytes / max(blur_n, 1))
