@@ -69,6 +69,8 @@ def lib():
         L.so_refine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.so_orientations.restype = C.c_int
         L.so_orientations.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.so_orientation_histogram.restype = None
+        L.so_orientation_histogram.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.so_descriptors.restype = C.c_int
         L.so_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int]
@@ -164,6 +166,12 @@ class Oracle:
         out = np.zeros(len(kp), orientation_dtype)
         n = self.L.so_orientations(self.h, o, _ptr(kp), len(kp), _ptr(out), len(out))
         return out[:n].copy()
+
+    def orientation_histogram(self, o, kp_record):
+        k = np.ascontiguousarray(np.array([kp_record], dtype=keypoint_dtype))
+        h = np.zeros(36, np.float32)
+        self.L.so_orientation_histogram(self.h, o, _ptr(k), _ptr(h))
+        return h
 
     def descriptors(self, o, kp, ori, want_float=False):
         kp = np.ascontiguousarray(kp)

@@ -545,7 +545,7 @@ static inline void gradient_at(const float *g, int w, int h, int gx, int gy, flo
 /* ---------------------------------------------------------------------------------------------
  * SIFTOctave.getKeypointOrientations (SIFTOctave.swift:290-382: host border filter, Int32
  * truncation of the absolute coordinates) + Sources/MetalShaders/Metal/SIFTOrientation.metal   */
-static void orientation_one(const so_ctx *c, int o, const so_keypoint *kpk, int k, so_orientation *res_out) {
+static void orientation_one(const so_ctx *c, int o, const so_keypoint *kpk, int k, so_orientation *res_out, float *hist_out) {
     const so_octave *q = &c->oct[o];
     const float delta = q->delta, lambda = 1.5f, orientationThreshold = 0.8f;   /* SIFTOctave.swift:296-300 */
     const size_t npx = (size_t)q->w * q->h;
@@ -589,6 +589,7 @@ static void orientation_one(const so_ctx *c, int o, const so_keypoint *kpk, int 
             }
         }
     }
+    if (hist_out) memcpy(hist_out, histogram, sizeof(histogram));      /* smoothed histogram (test hook) */
     so_orientation res;
     memset(&res, 0, sizeof(res));
     res.keypoint = k;
@@ -615,6 +616,12 @@ static void orientation_one(const so_ctx *c, int o, const so_keypoint *kpk, int 
     *res_out = res;
 }
 
+/* test hook: the 36-bin histogram after the 6 smoothing passes, for one keypoint (no border filter) */
+void so_orientation_histogram(const so_ctx *c, int o, const so_keypoint *kp, float *hist36) {
+    so_orientation tmp;
+    orientation_one(c, o, kp, 0, &tmp, hist36);
+}
+
 int so_orientations(const so_ctx *c, int o, const so_keypoint *kp, int n, so_orientation *out, int cap) {
     const so_octave *q = &c->oct[o];
     const float delta = q->delta, lambda = 1.5f;
@@ -635,7 +642,7 @@ int so_orientations(const so_ctx *c, int o, const so_keypoint *kp, int n, so_ori
     }
     const int nw = (out ? (count < cap ? count : cap) : 0);
 #pragma omp parallel for schedule(dynamic, 8)
-    for (int i = 0; i < nw; i++) orientation_one(c, o, &kp[pass[i]], pass[i], &out[i]);
+    for (int i = 0; i < nw; i++) orientation_one(c, o, &kp[pass[i]], pass[i], &out[i], NULL);
     free(pass);
     return count;
 }

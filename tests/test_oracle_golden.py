@@ -133,6 +133,31 @@ def test_descriptors_loose_vs_ipol(butterfly_oracle, ipol):
     assert (l2 < 200).mean() > 0.75 and np.median(l2) < 150
 
 
+def test_orientation_histograms_vs_ipol(butterfly_oracle, ipol):
+    """butterfly-descriptors.txt also holds IPOL's 36-bin orientation histogram per keypoint (last 36
+    columns).  The smoothed histogram of the restatement (window radius, Gaussian weighting, gradient
+    convention atan2(dx, dy), 6 box-smoothing passes) correlates with it bin for bin: median Pearson r > 0.98
+    over the co-located keypoints, best at zero circular shift."""
+    orc, res = butterfly_oracle
+    gy, gh = ipol["desc_yxst"], ipol["desc_orihist"].astype(np.float64)
+    rs = {-1: [], 0: [], 1: []}
+    for o in range(5):
+        for k in res[o]["keypoints"]:
+            d = np.hypot(gy[:, 0] - k["absY"], gy[:, 1] - k["absX"])
+            j = int(d.argmin())
+            if d[j] > 0.05:
+                continue
+            h = orc.orientation_histogram(o, k).astype(np.float64)
+            if h.max() <= 0:
+                continue
+            for sft in rs:
+                rs[sft].append(np.corrcoef(np.roll(h, sft), gh[j])[0, 1])
+    assert len(rs[0]) > 1200
+    med = {sft: float(np.median(v)) for sft, v in rs.items()}
+    assert med[0] > 0.98 and med[0] > med[1] + 0.03 and med[0] > med[-1] + 0.03, med
+    assert np.mean(np.array(rs[0]) > 0.9) > 0.85
+
+
 def test_fma_switch_is_within_float_noise(butterfly_bgra, butterfly_oracle):
     """fmaf vs mul+add in the tap loop: pyramid differs by float noise only (< 2e-6), same
     extrema counts -- so the choice is parity-neutral (DESIGN.md 'float policy')."""
