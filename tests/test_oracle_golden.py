@@ -115,7 +115,7 @@ def test_descriptors_loose_vs_ipol(butterfly_oracle, ipol):
     assert 480 < np.median(nrm) < 520
     g_yx, g_th, g_f = ipol["desc_yxst"][:, :2], ipol["desc_yxst"][:, 3], ipol["desc_features"].astype(np.float64)
     d = np.sqrt(((kps[:, None, :] - g_yx[None]) ** 2).sum(-1))
-    l2, dth = [], []
+    l2, dth, cosv = [], [], []
     for i in range(len(kps)):
         cand = np.where(d[i] < 0.05)[0]
         if len(cand) == 0:
@@ -127,7 +127,12 @@ def test_descriptors_loose_vs_ipol(butterfly_oracle, ipol):
             continue
         dth.append(dd[np.abs(dd).argmin()])
         l2.append(np.sqrt(((feats[i] - g_f[j]) ** 2).sum()))
-    l2, dth = np.array(l2), np.array(dth)
+        a = feats[i].astype(np.float64)
+        cosv.append(a @ g_f[j] / np.linalg.norm(a) / np.linalg.norm(g_f[j]))
+    l2, dth, cosv = np.array(l2), np.array(dth), np.array(cosv)
+    # same cell order, orientation-bin order and rotation convention as IPOL's 128 integers (a wrong layout
+    # would give cosines near 0.3): median cosine similarity 0.97, 96 % above 0.9
+    assert np.median(cosv) > 0.96 and (cosv > 0.9).mean() > 0.94
     assert len(l2) > 1200
     assert abs(np.median(dth) - (-0.0873)) < 0.01
     assert (l2 < 200).mean() > 0.75 and np.median(l2) < 150
