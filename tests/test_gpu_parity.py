@@ -126,6 +126,27 @@ def test_butterfly_against_ipol_fixtures(sm, butterfly_bgra, ipol):
     d = np.sqrt(((ours[:, None] - gold[None]) ** 2).sum(-1))
     assert (d.min(1) < 0.01).mean() >= 0.98
     assert (d.min(0) < 0.5).mean() >= 0.985
+    # descriptors of the HIP path against IPOL's 128 integers: layout / conventions (median cosine 0.97)
+    ds, dc = eng.describe(kps, counts)
+    g_yx, g_th, g_f = ipol["desc_yxst"][:, :2], ipol["desc_yxst"][:, 3], ipol["desc_features"].astype(np.float64)
+    pos, cosv = 0, []
+    kp_oct = _split(kps, counts)
+    for o, n in enumerate(dc):
+        for r in ds[pos:pos + n]:
+            k = kp_oct[o][r["keypoint"]]
+            dd = np.hypot(g_yx[:, 0] - k["abs_y"], g_yx[:, 1] - k["abs_x"])
+            cand = np.where(dd < 0.05)[0]
+            if len(cand) == 0:
+                continue
+            t = (r["theta"] + np.pi) % (2 * np.pi) - np.pi
+            da = np.abs((t - g_th[cand] + np.pi) % (2 * np.pi) - np.pi)
+            if da.min() > 0.3:
+                continue
+            a = r["features"].astype(np.float64)
+            b = g_f[cand[da.argmin()]]
+            cosv.append(a @ b / np.linalg.norm(a) / np.linalg.norm(b))
+        pos += n
+    assert len(cosv) > 1200 and np.median(cosv) > 0.96 and (np.array(cosv) > 0.9).mean() > 0.94
     # exact raw-extrema known answer with the 26-neighbour switch (extra_NES_butterfly.txt: 3068 rows)
     eng26 = sm.Engine(512, 340, n_octaves=5, full_neighbourhood=1)
     eng26.detect(butterfly_bgra)
