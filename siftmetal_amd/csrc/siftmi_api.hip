@@ -101,6 +101,11 @@ struct siftmi_ctx {
     } gkey{};
     hipGraphExec_t gexec = nullptr;
     bool graph_failed = false;
+    // fork/join of the octave chains inside a captured graph (small launches only, see run_dense_detect)
+    hipStream_t oct_stream[MAX_OCT] = {};
+    hipEvent_t ev_fork[MAX_OCT] = {}, ev_join[MAX_OCT] = {};
+    bool fork_ready = false;
+    hipStream_t tstream = nullptr;            // stream the timing events are recorded on
     // timings
     bool timing = false;
     std::vector<EventPair> pending, pool;
@@ -167,6 +172,11 @@ static void free_ctx(siftmi_ctx *c) {
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    for (int i = 0; i < MAX_OCT; i++) {
+        if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (c->oct_stream[i]) (void)hipStreamDestroy(c->oct_stream[i]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -288,12 +298,12 @@ static void t_begin(siftmi_ctx *c, int stage) {
     if (!c->pool.empty()) { ep = c->pool.back(); c->pool.pop_back(); }
     else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
     ep.stage = stage;
-    (void)hipEventRecord(ep.a, c->stream);
+    (void)hipEventRecord(ep.a, c->tstream ? c->tstream : c->stream);
     c->pending.push_back(ep);
 }
 static void t_end(siftmi_ctx *c) {
     if (!c->timing) return;
-    (void)hipEventRecord(c->pending.back().b, c->stream);
+    (void)hipEventRecord(c->pending.back().b, c->tstream ? c->tstream : c->stream);
 }
 static void t_collect(siftmi_ctx *c) {
     for (auto &ep : c->pending) {
@@ -364,56 +374,89 @@ static float *gauss_ptr(siftmi_ctx *c, int o, int s) {
     return c->d_gauss + c->P.oct_offset[o] + (size_t)s * c->ow[o] * c->oh[o];
 }
 
-// dense front end for nf frames: seed -> per-octave layer blurs (DifferenceOfGaussians.swift:346-406)
-static int run_dense(siftmi_ctx *c, hipStream_t st, int nf, const void *d_pixels, int format, size_t row_stride, size_t frame_stride) {
+static int32_t *cnt(siftmi_ctx *c, int which) { return c->d_counters + (size_t)which * c->B * c->n_oct; }
+enum { C_RAW = 0, C_CAND = 1, C_KP = 2, C_ORIENTED = 3, C_DESC = 4 };
+
+static int ensure_fork(siftmi_ctx *c) {
+    if (c->fork_ready) return SIFTMI_OK;
+    for (int i = 0; i < c->n_oct; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->oct_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    c->fork_ready = true;
+    return SIFTMI_OK;
+}
+
+static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
+    const int EH = 33;                                  // multiple of 3: the row loop is unrolled 3x
+    if (c->ow[o] < 3 || c->oh[o] < 3) return SIFTMI_OK;
+    t_begin(c, SIFTMI_T_EXTREMA);
+    dim3 grid((c->ow[o] - 2 + EXT_COLS_PER_BLOCK - 1) / EXT_COLS_PER_BLOCK, (c->oh[o] - 2 + EH - 1) / EH, nf);
+#define LAUNCH_EXT(NS) hipLaunchKernelGGL((extrema_kernel<NS>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW))
+    switch (c->nspo) {
+        case 1: LAUNCH_EXT(1); break;
+        case 2: LAUNCH_EXT(2); break;
+        case 3: LAUNCH_EXT(3); break;
+        case 4: LAUNCH_EXT(4); break;
+        default: LAUNCH_EXT(5); break;
+    }
+#undef LAUNCH_EXT
+    HIP_TRY(hipGetLastError());
+    t_end(c);
+    return SIFTMI_OK;
+}
+
+// Dense front end + extrema for nf frames (DifferenceOfGaussians.swift:346-406, SIFTOctave.swift:177-196):
+// seed -> per octave {layer blurs; the one writing layer nspo also emits the next octave's layer 0} -> extrema.
+// Octave o+1 depends on octave o only through that layer, so when `fork` is set (graph capture of a small
+// launch, e.g. ONE frame) the rest of octave o (its last layers and its extrema scan) stays on the current
+// stream while octave o+1 continues on another one; everything joins before refinement.  Large batches fill
+// the chip with every launch and gain nothing from this (tools/two_stream_probe.py), so they stay serial.
+static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d_pixels, int format, size_t row_stride, size_t frame_stride,
+                            bool fork) {
     const int NG = c->nspo + 3;
+    int rc;
+    if (fork && (rc = ensure_fork(c))) return rc;
     SeedSource seed;
     seed.pixels = (const unsigned char *)d_pixels; seed.frame_stride = frame_stride; seed.row_stride = row_stride;
     seed.format = format; seed.in_w = c->cfg.width; seed.in_h = c->cfg.height;
     SeedSource none; memset(&none, 0, sizeof(none));
     Decimate nodec; memset(&nodec, 0, sizeof(nodec));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 5 * (size_t)c->B * c->n_oct * sizeof(int32_t), st));
     t_begin(c, SIFTMI_T_SEED);
     HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed, nodec)));
     t_end(c);
+    hipStream_t cur = st;
+    bool joined[MAX_OCT] = {};
     for (int o = 0; o < c->n_oct; o++) {
+        hipStream_t next = cur;
         for (int s = 1; s < NG; s++) {
-            // the blur that produces layer nspo also emits the next octave's layer 0 (even pixels)
             Decimate dec = nodec;
             if (s == c->nspo && o + 1 < c->n_oct) {
                 dec.dst = gauss_ptr(c, o + 1, 0); dec.frame_stride = c->frame_stride; dec.w2 = c->ow[o + 1]; dec.h2 = c->oh[o + 1];
             }
             t_begin(c, SIFTMI_T_BLUR);
-            HIP_TRY((launch_blur<false>(c, st, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
+            HIP_TRY((launch_blur<false>(c, cur, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
                                         nf, c->layer_w[s - 1], none, dec)));
             t_end(c);
+            if (fork && s == c->nspo && o + 1 < c->n_oct) {          // next octave can start now, on its own stream
+                HIP_TRY(hipEventRecord(c->ev_fork[o], cur));
+                next = c->oct_stream[o + 1];
+                HIP_TRY(hipStreamWaitEvent(next, c->ev_fork[o], 0));
+            }
         }
+        if ((rc = launch_extrema(c, cur, nf, o))) return rc;
+        if (cur != st) { HIP_TRY(hipEventRecord(c->ev_join[o], cur)); joined[o] = true; }
+        cur = next;
     }
+    for (int o = 0; o < c->n_oct; o++)
+        if (joined[o]) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[o], 0));
     return SIFTMI_OK;
 }
 
-static int32_t *cnt(siftmi_ctx *c, int which) { return c->d_counters + (size_t)which * c->B * c->n_oct; }
-enum { C_RAW = 0, C_CAND = 1, C_KP = 2, C_ORIENTED = 3, C_DESC = 4 };
-
-// extrema -> refine -> sort  (SIFT.swift:147-202)
-static int run_detect(siftmi_ctx *c, hipStream_t st, int nf) {
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 5 * (size_t)c->B * c->n_oct * sizeof(int32_t), st));
-    const int EH = 33;                                  // multiple of 3: the row loop is unrolled 3x
-    for (int o = 0; o < c->n_oct; o++) {
-        if (c->ow[o] < 3 || c->oh[o] < 3) continue;
-        t_begin(c, SIFTMI_T_EXTREMA);
-        dim3 grid((c->ow[o] - 2 + EXT_COLS_PER_BLOCK - 1) / EXT_COLS_PER_BLOCK, (c->oh[o] - 2 + EH - 1) / EH, nf);
-#define LAUNCH_EXT(NS) hipLaunchKernelGGL((extrema_kernel<NS>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW))
-        switch (c->nspo) {
-            case 1: LAUNCH_EXT(1); break;
-            case 2: LAUNCH_EXT(2); break;
-            case 3: LAUNCH_EXT(3); break;
-            case 4: LAUNCH_EXT(4); break;
-            default: LAUNCH_EXT(5); break;
-        }
-#undef LAUNCH_EXT
-        HIP_TRY(hipGetLastError());
-        t_end(c);
-    }
+// refine -> sort  (SIFT.swift:190-202)
+static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
     const int groups = nf * c->n_oct;
     t_begin(c, SIFTMI_T_REFINE);
     hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
@@ -485,14 +528,15 @@ static int check_format(siftmi_ctx *c, int format, size_t row_stride) {
 // the launch sequence of one batched call (all sub-batches); everything asynchronous on `st`
 static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const void *d_pixels, int format, size_t row_stride,
                          size_t frame_stride, KeypointRec *d_kp, long long kp_cap, DescriptorRec *d_desc, long long desc_cap,
-                         int32_t *d_counts, int32_t *d_totals) {
+                         int32_t *d_counts, int32_t *d_totals, bool fork) {
     int rc;
+    c->tstream = st;
     HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
-        if ((rc = run_dense(c, st, nf, px, format, row_stride, frame_stride))) return rc;
-        if ((rc = run_detect(c, st, nf))) return rc;
+        if ((rc = run_dense_detect(c, st, nf, px, format, row_stride, frame_stride, fork))) return rc;
+        if ((rc = run_refine(c, st, nf))) return rc;
         if ((rc = run_describe(c, st, nf))) return rc;
         if ((rc = run_pack(c, st, nf, f0, n_frames, d_kp, kp_cap, d_desc, desc_cap, d_counts, c->d_stats))) return rc;
         c->last_sub_frames = nf;
@@ -522,8 +566,10 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
+                // fork the octave chains only for small launches (the first octave has fewer tiles than ~4 per CU)
+                const bool fork = c->n_oct > 1 && (long long)std::min(c->B, (int)n_frames) * c->ow[0] * c->oh[0] <= 16ll * 1024 * 1024;
                 rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
-                                   (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals);
+                                   (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals, fork);
                 e = hipStreamEndCapture(st, &graph);
                 if (rc == SIFTMI_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
                 else if (rc == SIFTMI_OK && e == hipSuccess) e = hipErrorUnknown;
@@ -546,7 +592,7 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
         }
     }
     rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
-                       (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals);
+                       (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals, false);
     if (rc) return rc;
     c->last_frames = n_frames;
     c->pyramid_valid = true;
@@ -614,14 +660,15 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     if ((rc = grow_outputs(c, kp_need, desc_need))) return rc;
     if ((rc = ensure_stats(c, n_frames))) return rc;
     hipStream_t st = c->stream;
+    c->tstream = st;
     HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const void *d_px; size_t d_row, d_frame;
         const unsigned char *src = (const unsigned char *)pixels + (size_t)f0 * frame_stride;
         if ((rc = stage_input(c, nf, src, format, row_stride, frame_stride, on_device, &d_px, &d_row, &d_frame))) return rc;
-        if ((rc = run_dense(c, st, nf, d_px, format, d_row, d_frame))) return rc;
-        if ((rc = run_detect(c, st, nf))) return rc;
+        if ((rc = run_dense_detect(c, st, nf, d_px, format, d_row, d_frame, false))) return rc;
+        if ((rc = run_refine(c, st, nf))) return rc;
         if ((rc = run_describe(c, st, nf))) return rc;
         if ((rc = run_pack(c, st, nf, f0, n_frames, c->d_out_kp, c->out_kp_cap, c->d_out_desc, c->out_desc_cap, c->d_out_counts, c->d_stats)))
             return rc;
@@ -657,10 +704,11 @@ extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    c->tstream = st;
     const void *d_px; size_t d_row, d_frame;
     if ((rc = stage_input(c, 1, pixels, format, row_stride, 0, on_device, &d_px, &d_row, &d_frame))) return rc;
-    if ((rc = run_dense(c, st, 1, d_px, format, d_row, d_frame))) return rc;
-    if ((rc = run_detect(c, st, 1))) return rc;
+    if ((rc = run_dense_detect(c, st, 1, d_px, format, d_row, d_frame, false))) return rc;
+    if ((rc = run_refine(c, st, 1))) return rc;
     std::vector<int32_t> h(5 * (size_t)c->B * c->n_oct);
     HIP_TRY(hipMemcpyAsync(h.data(), c->d_counters, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -697,6 +745,7 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
     if (!c->pyramid_valid) return set_error(SIFTMI_E_STATE, "siftmi_describe needs a preceding siftmi_detect on this context");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    c->tstream = st;
     const size_t cs = (size_t)c->B * c->n_oct;
     std::vector<int32_t> h(cs, 0);
     size_t pos = 0;
