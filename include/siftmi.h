@@ -171,6 +171,17 @@ int siftmi_detect_describe_batch_device(siftmi_ctx *ctx, int32_t n_frames, const
                                         siftmi_descriptor *d_descriptors, int64_t desc_capacity,
                                         int32_t *d_counts, int32_t *d_totals, void *stream);
 
+/* --- next row: SIFTDescriptor.match(source:target:absoluteThreshold:relativeThreshold:)
+   (SIFT/SIFTDescriptor.swift:298-361), brute force + ratio test.  siftmi_match replaces
+   SIFTCorrespondence (SIFT/SIFTCorrespondence.swift:11-16) with indices into the two input lists.
+   Matches come back in source order.  Pointers are host (on_device = 0) or device (1) memory.
+   The reference's defaults are absoluteThreshold 1.176, relativeThreshold 0.6. */
+typedef struct siftmi_match { int32_t source, target; float distance; } siftmi_match;
+int siftmi_match_descriptors(siftmi_ctx *ctx, const siftmi_descriptor *source, int64_t n_source,
+                             const siftmi_descriptor *target, int64_t n_target, int on_device,
+                             float absolute_threshold, float relative_threshold,
+                             const siftmi_match **matches, int64_t *count);
+
 /* --- record conversion (SIFTOctave.swift:470-489 host unpack) -------------------------------- */
 void siftmi_descriptor_to_reference(const siftmi_descriptor *in, int64_t n, siftmi_descriptor_reference *out);
 

@@ -77,6 +77,8 @@ def lib():
         L.so_detect_describe.restype = C.c_int
         L.so_detect_describe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         L.so_num_threads.restype = C.c_int
+        L.so_match.restype = C.c_int
+        L.so_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -202,6 +204,18 @@ class Oracle:
                         "descriptors": d[0] if want_float else d,
                         "features_f32": d[1] if want_float else None})
         return res
+
+
+match_dtype = np.dtype([("source", "<i4"), ("target", "<i4"), ("distance", "<f4")])
+
+
+def match(src_features, tgt_features, absolute_threshold=1.176, relative_threshold=0.6):
+    """SIFTDescriptor.match on [n,128] integer feature arrays -> structured array of correspondences."""
+    a = np.ascontiguousarray(src_features, dtype=np.int32)
+    b = np.ascontiguousarray(tgt_features, dtype=np.int32)
+    out = np.zeros(max(len(a), 1), match_dtype)
+    n = lib().so_match(_ptr(a), len(a), _ptr(b), len(b), absolute_threshold, relative_threshold, _ptr(out), len(out))
+    return out[:n].copy()
 
 
 def num_threads():

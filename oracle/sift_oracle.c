@@ -794,3 +794,47 @@ int so_detect_describe(so_ctx *c, const void *pixels, int format, int stride,
     }
     return total;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Sources/SIFTMetal/SIFT/SIFTDescriptor.swift:298-361  SIFTDescriptor.match (brute force + ratio test)
+ * distance = FloatVector.distance (Utilities/Vector.swift:226-239: sqrt(vDSP.distanceSquared)) between the
+ * two descriptors' indexValue = rawFeatures (features / 255 as Float, SIFTDescriptor.swift:36-40) in a
+ * permuted cell order (:42-80; a permutation does not change the distance).  vDSP's summation order is
+ * not documented; restated as a sequential f32 sum.
+ * The scan keeps `second` = the running best at the moment the final best was found (it is NOT updated by
+ * a distance that falls between best and second, :333-337), so it equals the minimum over the targets
+ * BEFORE the best one -- FLT_MAX when the best is the first target.                                   */
+int so_match(const int32_t *src /* [n_src][128] */, int n_src, const int32_t *tgt /* [n_tgt][128] */, int n_tgt,
+             float absoluteThreshold, float relativeThreshold, so_match_rec *out, int cap) {
+    int count = 0;
+    float *traw = (float *)malloc(sizeof(float) * (size_t)(n_tgt > 0 ? n_tgt : 1) * SO_DESC_FEATURES);
+    for (long i = 0; i < (long)n_tgt * SO_DESC_FEATURES; i++) traw[i] = (float)tgt[i] / 255.0f;
+    so_match_rec *res = (so_match_rec *)malloc(sizeof(so_match_rec) * (size_t)(n_src > 0 ? n_src : 1));
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int s = 0; s < n_src; s++) {
+        float a[SO_DESC_FEATURES];
+        for (int i = 0; i < SO_DESC_FEATURES; i++) a[i] = (float)src[(size_t)s * SO_DESC_FEATURES + i] / 255.0f;
+        int best = -1;
+        float bestD = 3.402823466e+38f, secondD = 0.0f;
+        int haveSecond = 0;
+        for (int t = 0; t < n_tgt; t++) {
+            const float *b = traw + (size_t)t * SO_DESC_FEATURES;
+            float d2 = 0.0f;
+            for (int i = 0; i < SO_DESC_FEATURES; i++) { const float d = a[i] - b[i]; d2 += d * d; }
+            const float distance = sqrtf(d2);
+            if (distance < bestD) { best = t; secondD = bestD; haveSecond = 1; bestD = distance; }
+        }
+        res[s].source = s; res[s].target = -1; res[s].distance = bestD;
+        if (best < 0 || !haveSecond) continue;
+        if (!(bestD < absoluteThreshold)) continue;
+        if (!(bestD < secondD * relativeThreshold)) continue;
+        res[s].target = best;
+    }
+    for (int s = 0; s < n_src; s++) {
+        if (res[s].target < 0) continue;
+        if (out && count < cap) out[count] = res[s];
+        count++;
+    }
+    free(res); free(traw);
+    return count;
+}

@@ -107,6 +107,11 @@ int so_detect_describe(so_ctx *c, const void *pixels, int format, int row_stride
                        int32_t *n_extrema, int32_t *n_keypoints, int32_t *n_oriented,
                        int32_t *n_descriptors);
 
+/* SIFTDescriptor.match (SIFT/SIFTDescriptor.swift:298-361): brute force + ratio test, matches in source order */
+typedef struct { int32_t source, target; float distance; } so_match_rec;
+int so_match(const int32_t *src, int n_src, const int32_t *tgt, int n_tgt, float absoluteThreshold, float relativeThreshold,
+             so_match_rec *out, int cap);
+
 int so_num_threads(void);
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@ from . import _capi
 from ._capi import (FMT_BGRA8, FMT_GRAY8, FMT_GRAYF32, SiftmiError, descriptor_dtype, extremum_dtype,  # noqa: F401
                     keypoint_dtype, orientation_dtype)
 
-__all__ = ["SIFT", "SIFTKeypoint", "SIFTDescriptor", "IntegralSize", "SiftmiError", "Engine"]
+__all__ = ["SIFT", "SIFTKeypoint", "SIFTDescriptor", "SIFTCorrespondence", "IntegralSize", "SiftmiError", "Engine"]
 
 
 @dataclass(frozen=True)
@@ -51,6 +51,13 @@ class SIFTDescriptor:                    # SIFT/SIFTDescriptor.swift:12-40
     def __post_init__(self):
         if not self.rawFeatures:
             self.rawFeatures = [np.float32(f) / np.float32(255) for f in self.features]
+
+
+@dataclass
+class SIFTCorrespondence:                # SIFT/SIFTCorrespondence.swift:11-16
+    source: SIFTDescriptor
+    target: SIFTDescriptor
+    featureDistance: float
 
 
 def _fmt_of(img):
@@ -147,6 +154,18 @@ class Engine:
         """All pointers are device addresses (ints); asynchronous on `stream`."""
         _capi.check(self.L.siftmi_detect_describe_batch_device(self.h, n_frames, d_pixels, fmt, row_stride, frame_stride, d_kp, kp_cap,
                                                                d_desc, desc_cap, d_counts, d_totals, stream))
+
+    # ---- SIFTDescriptor.match (next row, SURVEY 8f) ----
+    def match(self, source, target, absolute_threshold=1.176, relative_threshold=0.6):
+        """source / target: siftmi descriptor records (descriptor_dtype).  Returns match records in source order."""
+        a = np.ascontiguousarray(source, dtype=descriptor_dtype)
+        b = np.ascontiguousarray(target, dtype=descriptor_dtype)
+        out, n = C.c_void_p(), C.c_int64()
+        _capi.check(self.L.siftmi_match_descriptors(self.h, a.ctypes.data, len(a), b.ctypes.data, len(b), 0, absolute_threshold,
+                                                    relative_threshold, C.byref(out), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, _capi.match_dtype)
+        return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 12,)).view(_capi.match_dtype).copy()
 
     # ---- introspection ----
     def stats(self):
@@ -258,6 +277,19 @@ class SIFT:
                         for r in ds[pos:pos + dc[o]]])
             pos += dc[o]
         return out
+
+    def match(self, source: List[SIFTDescriptor], target: List[SIFTDescriptor], absoluteThreshold: float = 1.176,
+              relativeThreshold: float = 0.6) -> List["SIFTCorrespondence"]:
+        """SIFTDescriptor.match(source:target:absoluteThreshold:relativeThreshold:) (SIFTDescriptor.swift:298-318);
+        a static function in the reference, hosted on the SIFT object here because it needs the device context."""
+        def pack(ds):
+            out = np.zeros(len(ds), descriptor_dtype)
+            for i, d in enumerate(ds):
+                out[i]["theta"] = d.theta
+                out[i]["features"] = d.features
+            return out
+        m = self._engine.match(pack(source), pack(target), absoluteThreshold, relativeThreshold)
+        return [SIFTCorrespondence(source[int(r["source"])], target[int(r["target"])], float(r["distance"])) for r in m]
 
     # BASELINE.json's north_star names the API detect()/describe(); keep them as aliases.
     detect = getKeypoints

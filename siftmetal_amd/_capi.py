@@ -15,7 +15,7 @@ T_NAMES = ["seed", "blur", "downsample", "extrema", "refine", "sort", "orient", 
 EXPORTS = [
     "siftmi_default_config", "siftmi_create", "siftmi_destroy", "siftmi_last_error", "siftmi_device_count",
     "siftmi_detect", "siftmi_describe", "siftmi_detect_describe_batch", "siftmi_detect_describe_batch_device",
-    "siftmi_descriptor_to_reference", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
+    "siftmi_descriptor_to_reference", "siftmi_match_descriptors", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
     "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_extrema", "siftmi_copy_orientations",
     "siftmi_copy_descriptor_floats", "siftmi_enable_timings", "siftmi_reset_timings", "siftmi_get_timings",
     "siftmi_blur_algorithmic_bytes", "siftmi_time_blur", "siftmi_synchronize",
@@ -44,6 +44,7 @@ keypoint_dtype = np.dtype([("octave", "<i4"), ("scale", "<i4"), ("sub_scale", "<
                            ("sigma", "<f4"), ("value", "<f4")])
 orientation_dtype = np.dtype([("keypoint", "<i4"), ("count", "<i4"), ("orientations", "<f4", (36,))])
 descriptor_dtype = np.dtype([("keypoint", "<i4"), ("theta", "<f4"), ("features", "u1", (128,))])
+match_dtype = np.dtype([("source", "<i4"), ("target", "<i4"), ("distance", "<f4")])
 descriptor_reference_dtype = np.dtype([("valid", "<i4"), ("keypoint", "<i4"), ("theta", "<f4"), ("features", "<i4", (128,))])
 assert keypoint_dtype.itemsize == 44 and descriptor_dtype.itemsize == 136
 assert orientation_dtype.itemsize == 152 and descriptor_reference_dtype.itemsize == 524
@@ -79,6 +80,7 @@ def load():
                                                C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.siftmi_detect_describe_batch_device.argtypes = [vp, C.c_int32, vp, C.c_int, C.c_size_t, C.c_size_t,
                                                       vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
+    L.siftmi_match_descriptors.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.siftmi_descriptor_to_reference.argtypes = [vp, C.c_int64, vp]
     L.siftmi_descriptor_to_reference.restype = None
     L.siftmi_get_stats.argtypes = [vp, C.POINTER(Stats)]

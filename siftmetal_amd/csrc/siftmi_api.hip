@@ -23,6 +23,7 @@
 #include "../../include/siftmi.h"
 #include "dense_kernels.hip.h"
 #include "keypoint_kernels.hip.h"
+#include "match_kernels.hip.h"
 
 using namespace siftmi;
 
@@ -85,6 +86,9 @@ struct siftmi_ctx {
     std::vector<siftmi_keypoint> h_kp;
     std::vector<siftmi_descriptor> h_desc;
     std::vector<int32_t> h_counts, h_stats;
+    std::vector<siftmi_match> h_matches;
+    DescriptorRec *d_match_src = nullptr, *d_match_tgt = nullptr; long long match_src_cap = 0, match_tgt_cap = 0;
+    MatchRec *d_match_out = nullptr; long long match_out_cap = 0;
     int last_frames = 0;                      // frames of the last batch call
     int last_sub_frames = 0;                  // frames resident in the pyramid
     bool pyramid_valid = false;
@@ -167,7 +171,7 @@ static void free_ctx(siftmi_ctx *c) {
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_ori_count, c->d_ori_angles,
                     c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_state, c->d_out_kp,
-                    c->d_out_desc, c->d_out_counts, c->d_stats};
+                    c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -792,6 +796,51 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
     c->last_frames = 1;
     if (descriptors) *descriptors = c->h_desc.data();
     if (flags) return overflow_error(c, flags);
+    return SIFTMI_OK;
+}
+
+// SIFTDescriptor.match (SIFT/SIFTDescriptor.swift:298-361) -- see match_kernels.hip.h
+extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *source, int64_t n_source, const siftmi_descriptor *target,
+                                        int64_t n_target, int on_device, float absolute_threshold, float relative_threshold,
+                                        const siftmi_match **matches, int64_t *count) {
+    if (!c || !count || n_source < 0 || n_target < 0 || (n_source && !source) || (n_target && !target))
+        return set_error(SIFTMI_E_BADARG, "bad argument");
+    if (n_source > (1ll << 30) || n_target > (1ll << 30)) return set_error(SIFTMI_E_BADARG, "too many descriptors");
+    *count = 0;
+    c->h_matches.clear();
+    if (matches) *matches = c->h_matches.data();
+    if (n_source == 0 || n_target == 0) return SIFTMI_OK;                    // no target: every match is nil (:340-346)
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto grow = [&](void **p, long long *cap, long long need, size_t elem) -> int {
+        if (need <= *cap) return SIFTMI_OK;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; *cap = 0;
+        HIP_TRY(hipMalloc(p, (size_t)need * elem));
+        *cap = need;
+        return SIFTMI_OK;
+    };
+    int rc;
+    const DescriptorRec *d_src = (const DescriptorRec *)source, *d_tgt = (const DescriptorRec *)target;
+    if (!on_device) {
+        if ((rc = grow((void **)&c->d_match_src, &c->match_src_cap, n_source, sizeof(DescriptorRec)))) return rc;
+        if ((rc = grow((void **)&c->d_match_tgt, &c->match_tgt_cap, n_target, sizeof(DescriptorRec)))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_match_src, source, (size_t)n_source * sizeof(DescriptorRec), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_match_tgt, target, (size_t)n_target * sizeof(DescriptorRec), hipMemcpyHostToDevice, st));
+        d_src = c->d_match_src; d_tgt = c->d_match_tgt;
+    }
+    if ((rc = grow((void **)&c->d_match_out, &c->match_out_cap, n_source, sizeof(MatchRec)))) return rc;
+    const int blocks = (int)((n_source + MATCH_SRC_PER_BLOCK - 1) / MATCH_SRC_PER_BLOCK);
+    hipLaunchKernelGGL(match_kernel, dim3(blocks), dim3(256), 0, st, d_src, (int)n_source, d_tgt, (int)n_target, absolute_threshold,
+                       relative_threshold, c->d_match_out);
+    HIP_TRY(hipGetLastError());
+    std::vector<siftmi_match> all((size_t)n_source);
+    HIP_TRY(hipMemcpyAsync(all.data(), c->d_match_out, (size_t)n_source * sizeof(MatchRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (const siftmi_match &m : all)
+        if (m.target >= 0) c->h_matches.push_back(m);                        // source order (:304-314)
+    *count = (int64_t)c->h_matches.size();
+    if (matches) *matches = c->h_matches.data();
     return SIFTMI_OK;
 }
 

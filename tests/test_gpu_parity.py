@@ -399,3 +399,98 @@ def test_heavy_noise_never_overruns(sm):
     assert e.value.code == _capi.E_CAPACITY and "extrema" in str(e.value)
     k2, kc2, d2, dc2 = small.detect_describe_batch(img[None], allow_capacity=True)
     assert small.stats()["candidates"][0, 0] > 64 and len(k2) <= len(k)
+
+
+# ---------------------------------------------------------------- next row: SIFTDescriptor.match
+
+def _sift_like(rng, n, spread=40.0):
+    return np.clip(np.abs(rng.normal(0.0, spread, (n, 128))), 0, 255).astype(np.int32)
+
+
+def _records(sm, feats):
+    rec = np.zeros(len(feats), sm.descriptor_dtype)
+    rec["features"] = feats
+    rec["keypoint"] = np.arange(len(feats))
+    return rec
+
+
+def _assert_matches_equal(got, want):
+    """Indices bit-exact.  Distances: the product forms |a-b|^2 exactly in integers, the oracle sums f32 squares of
+    (a-b)/255 in order as vDSP-free restatement; they agree to f32 rounding."""
+    assert len(got) == len(want)
+    np.testing.assert_array_equal(got["source"], want["source"])
+    np.testing.assert_array_equal(got["target"], want["target"])
+    np.testing.assert_allclose(got["distance"], want["distance"], rtol=3e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_src,n_tgt", [(1, 1), (5, 3), (64, 64), (65, 257), (300, 1000), (2500, 2300)])
+def test_match_random_vs_oracle(sm, n_src, n_tgt):
+    from oracle import pyoracle
+    rng = np.random.default_rng(100 + n_src)
+    tgt = _sift_like(rng, n_tgt)
+    pick = rng.integers(0, n_tgt, n_src)
+    noise = rng.integers(-12, 13, (n_src, 128))
+    src = np.clip(tgt[pick] + noise, 0, 255).astype(np.int32)
+    src[::3] = _sift_like(rng, len(src[::3]))                 # a third without a true partner
+    eng = sm.Engine(64, 64, n_octaves=1)
+    n_found = []
+    for abs_thr, rel_thr in ((1.176, 0.6), (1.176, 0.9), (0.25, 0.8)):
+        got = eng.match(_records(sm, src), _records(sm, tgt), abs_thr, rel_thr)
+        want = pyoracle.match(src, tgt, abs_thr, rel_thr)
+        _assert_matches_equal(got, want)
+        n_found.append(len(want))
+    assert max(n_found) > 0 or n_src <= 5
+
+
+def test_match_ties_quirk_and_edges(sm):
+    from oracle import pyoracle
+    rng = np.random.default_rng(9)
+    eng = sm.Engine(64, 64, n_octaves=1)
+    f = _sift_like(rng, 70)
+    # exact duplicates spread over the 4 waves' target subsets and over LDS tiles: first index must win
+    tgt = np.concatenate([f, f, f[:10]])
+    got = eng.match(_records(sm, f), _records(sm, tgt), 1.176, 0.6)
+    want = pyoracle.match(f, tgt, 1.176, 0.6)
+    _assert_matches_equal(got, want)
+    assert np.all(got["target"] == got["source"]) and np.all(got["distance"] == 0)
+    # 'second' is the best of the targets BEFORE the best, not the true runner-up (SIFTDescriptor.swift:333-338)
+    a = np.zeros((1, 128), np.int32)
+    far, near, near2 = np.full(128, 100, np.int32), np.full(128, 2, np.int32), np.full(128, 3, np.int32)
+    for order, n_expected in (([far, near, near2], 1), ([far, near2, near], 0), ([near, near2, far], 1)):
+        t = np.stack(order)
+        got = eng.match(_records(sm, a), _records(sm, t))
+        _assert_matches_equal(got, pyoracle.match(a, t))
+        assert len(got) == n_expected
+    # extremes of the integer range: 128 * 255^2 fits, bias shift is exact
+    lo, hi = np.zeros((3, 128), np.int32), np.full((2, 128), 255, np.int32)
+    got = eng.match(_records(sm, lo), _records(sm, np.concatenate([hi, lo[:1]])), 100.0, 100.0)
+    assert list(got["target"]) == [2, 2, 2]
+    got = eng.match(_records(sm, lo), _records(sm, hi), 100.0, 100.0)
+    np.testing.assert_allclose(got["distance"], np.sqrt(128.0), rtol=1e-6)
+    # empty sides
+    assert len(eng.match(_records(sm, lo), _records(sm, lo[:0]))) == 0
+    assert len(eng.match(_records(sm, lo[:0]), _records(sm, lo))) == 0
+    eng.close()
+
+
+def test_match_real_frames_through_reference_api(sm):
+    """Two views of the same synthetic scene (second one shifted by 3 px): SIFT.match mirrors
+    SIFTDescriptor.match(source:target:) and agrees with the oracle matcher on the same descriptor lists."""
+    from oracle import pyoracle
+    a = blob_frame(640, 480, 0, n_blobs=300)
+    b = np.roll(a, (3, 3), axis=(0, 1))
+    sift = sm.SIFT(device=0, configuration=sm.SIFT.Configuration(inputSize=sm.IntegralSize(640, 480)))
+    da = [d for o in sift.getDescriptors(sift.getKeypoints(a)) for d in o]
+    db = [d for o in sift.getDescriptors(sift.getKeypoints(b)) for d in o]
+    assert len(da) > 200 and len(db) > 200
+    got = sift.match(da, db)
+    want = pyoracle.match(np.array([d.features for d in da]), np.array([d.features for d in db]))
+    assert [id(m.source) for m in got] == [id(da[int(w["source"])]) for w in want]
+    assert [id(m.target) for m in got] == [id(db[int(w["target"])]) for w in want]
+    np.testing.assert_allclose([m.featureDistance for m in got], want["distance"], rtol=3e-6, atol=1e-7)
+    # the matches are geometrically right: matched keypoints differ by the shift
+    dx = np.array([m.target.keypoint.absoluteCoordinate[0] - m.source.keypoint.absoluteCoordinate[0] for m in got])
+    dy = np.array([m.target.keypoint.absoluteCoordinate[1] - m.source.keypoint.absoluteCoordinate[1] for m in got])
+    assert len(got) > 100
+    ok = (np.abs(dx - 3) < 1.0) & (np.abs(dy - 3) < 1.0)
+    assert ok.mean() > 0.9
