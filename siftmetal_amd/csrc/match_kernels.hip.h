@@ -7,9 +7,10 @@
 //     if distance < best { second = best; best = distance; bestIndex = t }
 // so `second` is the running minimum at the moment the final best was found, i.e. the minimum over the
 // targets BEFORE the best one (FLT_MAX if the best is the first target) -- not the true second nearest.
-// That order dependence decomposes into two order-independent reductions:
-//     pass 1  (best, bestIndex) = argmin over all targets, smallest index on ties (strict '<' in the scan)
-//     pass 2  second = min over targets with index < bestIndex
+// Any CONTIGUOUS chunk of targets can be scanned on its own into (best, first index of best, second = minimum
+// over the chunk's targets before that index), and chunks combine in target order with
+//     if (b < best) { second = min(best, s); best = b; idx = i; }
+// which is how the kernel below parallelises the scan without changing its result.
 // Distances: the reference takes the f32 Euclidean distance of features/255; here the squared distance of
 // the 0..255 integers is formed exactly in int32 (bytes re-biased by 128 to signed i8, v_dot4_i32_i8:
 // |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b', shift-invariant) and distance = sqrt(D) / 255 in f32; the two agree
@@ -24,89 +25,199 @@ namespace siftmi {
 
 struct MatchRec { int32_t source, target; float distance; };          // == siftmi_match
 
-constexpr int MATCH_SRC_PER_BLOCK = 64;     // one source descriptor per lane, the 4 waves split the targets
-constexpr int MATCH_TILE = 64;              // targets staged in LDS per iteration
-
 __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 
-// one pass over all targets for the 64 sources of this block; PASS 1: argmin, PASS 2: min over index < limit
-template <int PASS>
-__device__ __forceinline__ void match_pass(const DescriptorRec *__restrict__ tgt, int n_tgt, const int (&a)[32], int na, int limit,
-                                           int *lds_t /* [MATCH_TILE][33] */, int &bestD, int &bestI) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    bestD = 0x7fffffff; bestI = -1;
-    for (int t0 = 0; t0 < n_tgt; t0 += MATCH_TILE) {
-        __syncthreads();
-        // stage MATCH_TILE targets: 32 re-biased dwords + |b'|^2 each
-        for (int i = threadIdx.x; i < MATCH_TILE * 32; i += 256) {
-            const int tt = i >> 5, k = i & 31;
-            int v = 0;
-            if (t0 + tt < n_tgt) v = reinterpret_cast<const int *>(tgt[t0 + tt].features)[k] ^ (int)0x80808080;
-            lds_t[tt * 33 + k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < MATCH_TILE) {
-            int nb = 0;
+// =====================================================================================================
+// MFMA matcher.  The distance matrix is a GEMM (|a-b|^2 = |a|^2 + |b|^2 - 2 a.b, K = 128 int8), so it runs on
+// the matrix cores: v_mfma_i32_32x32x32_i8, exact int32 accumulation.  A = 32 targets (LDS tile shared by the
+// block's 4 waves), B = 32 sources held in registers for the whole kernel (2 source tiles per wave, 256
+// sources per block).  With targets on the rows the C/D layout (col = lane&31, row = (reg&3) + 8(reg>>2) +
+// 4(lane>>5)) leaves one SOURCE per lane and 16 TARGETS in its accumulator registers, so the per-source scan is
+// lane-local.  The rows of a tile are assigned so that accumulator register i of lane half h is target
+// chunk_h + 16*tile + i: each lane walks a CONTIGUOUS chunk of targets in index order, which is what the
+// reference's order-dependent `second` needs (see the top of this file):
+//     lane state: best, idx (first minimum in the chunk), second = min over the chunk's targets before idx
+//     chunks combine in order:  if (b < best) { second = min(best, s); best = b; idx = i; }
+// (half 0 before half 1 inside a block, target splits across blockIdx.y in match_finalize_kernel).
+// The scan costs 16 mad + 8 min3 + 1 compare per 32x32 tile; the ordered 16-step update only runs when some
+// lane's tile minimum beats its best (O(log n) times per source).
+// =====================================================================================================
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MM_NB = 4;                                   // source tiles (of 32) per wave
+constexpr int MM_TT = 2;                                   // target tiles (of 32) staged per barrier
+constexpr int MM_SRC_PER_BLOCK = 32 * MM_NB * 4;           // 512
+constexpr int MM_SPLIT_QUANTUM = 32 * MM_TT;               // a split's target range is a multiple of this
+constexpr int MM_ROW = 144;                                // LDS row stride in bytes: 128 + 16 -> conflict-free ds_read_b128
+constexpr int MM_NONE = 0x7fffffff;
+constexpr int MM_PAD_NORM = 0x03ffffff;                    // |b|^2 of a padding row: its key can never win (and (acc << 5) still fits)
+constexpr int MM_PAD_LIMIT = 0x02000000;                   // real keys are below 2^23
+
+// features -> dense rows of 128 re-biased int8 (32 dwords) + |b'|^2.  32 threads per descriptor.
+__global__ __launch_bounds__(256) void match_prep_kernel(const DescriptorRec *__restrict__ d, int n, int *__restrict__ packed,
+                                                        int *__restrict__ norm) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(gid >> 5), k = (int)(gid & 31);
+    int v = 0;
+    if (i < n) {
+        v = reinterpret_cast<const int *>(d[i].features)[k] ^ (int)0x80808080;
+        packed[(long long)i * 32 + k] = v;
+    }
+    int nb = dot4(v, v, 0);
 #pragma unroll
-            for (int k = 0; k < 32; k++) { const int v = lds_t[threadIdx.x * 33 + k]; nb = dot4(v, v, nb); }
-            lds_t[MATCH_TILE * 33 + threadIdx.x] = nb;
-        }
-        __syncthreads();
-        const int tend = min(MATCH_TILE, n_tgt - t0);
-        for (int tt = wv; tt < tend; tt += 4) {                 // this wave's targets of the tile, increasing index
-            const int gi = t0 + tt;
-            if (PASS == 2 && gi >= limit) break;                // only targets before this source's best (per lane)
-            int dot = 0;
+    for (int o = 1; o < 32; o <<= 1) nb += __shfl_xor(nb, o, 64);
+    if (i < n && k == 0) norm[i] = nb;
+}
+
+// amdgpu_waves_per_eu(2): caps the kernel at 256 VGPRs, which makes the compiler keep the MFMA results in VGPRs
+// (no v_accvgpr_read per element in the scan).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int *__restrict__ tgt_packed,
+                       const int *__restrict__ tgt_norm, int n_tgt, int split_len /* multiple of MM_SPLIT_QUANTUM */,
+                       int4 *__restrict__ part /* [gridDim.y][n_src]: best, idx, second */) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][MM_TT][32 * MM_ROW];
+    __shared__ __attribute__((aligned(16))) int lds_c[2][MM_TT][32];    // C-in of the MFMA chain: -(|b'|^2 >> 1)
+    __shared__ __attribute__((aligned(16))) int lds_n[2][MM_TT][32];    // |b'|^2 (only read on the ordered-update path)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int half_len = split_len >> 1, n_iter = half_len / (16 * MM_TT);
+    const int t_lo = blockIdx.y * split_len, t_hi = min(n_tgt, t_lo + split_len);
+    // sources of this wave: B operands, resident
+    i32x4 b[MM_NB][4];
+    const int s0 = blockIdx.x * MM_SRC_PER_BLOCK + wv * (32 * MM_NB);
 #pragma unroll
-            for (int k = 0; k < 32; k++) dot = dot4(a[k], lds_t[tt * 33 + k], dot);     // broadcast LDS reads
-            const int D = na + lds_t[MATCH_TILE * 33 + tt] - 2 * dot;
-            if (D < bestD) { bestD = D; bestI = gi; }           // strict: first index wins inside a wave's ordered subset
+    for (int nb = 0; nb < MM_NB; nb++) {
+        const int sc = min(s0 + nb * 32 + c, n_src - 1);
+#pragma unroll
+        for (int m = 0; m < 4; m++) b[nb][m] = *reinterpret_cast<const i32x4 *>(src_packed + (long long)sc * 32 + m * 8 + h * 4);
+    }
+    // staging role of this thread: tile row r (MFMA row), 16-byte piece p, of each of the MM_TT tiles
+    const int r = tid >> 3, p = tid & 7, hr = (r >> 2) & 1, pos = (r >> 3) * 4 + (r & 3);
+    const int st_base = t_lo + hr * half_len + pos, st_end = hr ? t_hi : min(t_hi, t_lo + half_len);
+    i32x4 pre_v[MM_TT]; int pre_n[MM_TT];
+    auto prefetch = [&](int it) {
+#pragma unroll
+        for (int j = 0; j < MM_TT; j++) {
+            const int t = st_base + (it * MM_TT + j) * 16;
+            const bool valid = t < st_end;
+            pre_v[j] = *reinterpret_cast<const i32x4 *>(tgt_packed + (long long)(valid ? t : 0) * 32 + p * 4);
+            pre_n[j] = MM_PAD_NORM;
+            if (p == 0 && valid) pre_n[j] = tgt_norm[t];
         }
-        (void)lane;
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MM_TT; j++) {
+            *reinterpret_cast<i32x4 *>(&lds_a[buf][j][r * MM_ROW + p * 16]) = pre_v[j];
+            if (p == 0) {
+                lds_c[buf][j][hr * 16 + pos] = -(pre_n[j] >> 1);
+                lds_n[buf][j][hr * 16 + pos] = pre_n[j];
+            }
+        }
+    };
+    // key = |b'|^2 - 2 a'.b' (the distance without the per-source constant |a'|^2).  The chain starts from
+    // C = -(|b'|^2 >> 1), so acc = a'.b' - (|b'|^2 >> 1) and key = (|b'|^2 & 1) - 2 acc.  Screening test on acc alone:
+    // key < best  =>  acc > floor(-best / 2) = thr  (exact up to the parity bit; the ordered path re-tests exactly).
+    int best[MM_NB], idx[MM_NB], second[MM_NB], thr[MM_NB];
+#pragma unroll
+    for (int nb = 0; nb < MM_NB; nb++) { best[nb] = MM_NONE; idx[nb] = -1; second[nb] = MM_NONE; thr[nb] = (-MM_NONE) >> 1; }
+
+    if (n_iter > 0) { prefetch(0); stage(0); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the source fragments have landed, so the loop's only VMEM waits are its prefetches
+    __syncthreads();
+    for (int it = 0; it < n_iter; it++) {
+        const int cur = it & 1;
+#ifndef MM_VARIANT_NO_LOAD
+        if (it + 1 < n_iter) prefetch(it + 1);
+#endif
+#pragma unroll
+        for (int j = 0; j < MM_TT; j++) {
+            i32x4 a[4];
+            i32x16 cin;
+#pragma unroll
+            for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const i32x4 *>(&lds_a[cur][j][c * MM_ROW + m * 32 + h * 16]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
+                cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
+            }
+            const int tbase = t_lo + h * half_len + (it * MM_TT + j) * 16;
+#pragma unroll
+            for (int nb0 = 0; nb0 < MM_NB; nb0 += 2) {       // two independent MFMA chains in flight, scans behind them
+                i32x16 acc[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], cin, 0, 0, 0);
+#pragma unroll
+                    for (int m = 1; m < 4; m++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[nb0 + u][m], acc[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int nb = nb0 + u;
+                    int tmax = acc[u][0];
+#pragma unroll
+                    for (int i = 1; i < 16; i++) tmax = max(tmax, acc[u][i]);
+#ifdef MM_VARIANT_NO_UPDATE
+                    if (tmax > 0x7ffffff0) best[nb] = tmax;
+#else
+                    if (tmax > thr[nb]) {                    // some lane may improve: ordered update, exactly the reference's scan
+                        int at = -1;
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const i32x4 pv = *reinterpret_cast<const i32x4 *>(&lds_n[cur][j][h * 16 + g * 4]);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int key = (pv[e] & 1) - 2 * acc[u][g * 4 + e];
+                                if (key < best[nb]) { second[nb] = best[nb]; best[nb] = key; at = g * 4 + e; }
+                            }
+                        }
+                        if (at >= 0) { idx[nb] = tbase + at; thr[nb] = (-best[nb]) >> 1; }
+                    }
+#endif
+                }
+            }
+        }
+#ifndef MM_VARIANT_NO_LOAD
+        if (it + 1 < n_iter) stage(cur ^ 1);
+#endif
+#ifndef MM_VARIANT_NO_BARRIER
+        __syncthreads();
+#endif
+    }
+    // padding rows and empty chunks -> none;  then half 0 (earlier chunk) with half 1
+#pragma unroll
+    for (int nb = 0; nb < MM_NB; nb++) {
+        if (best[nb] >= MM_PAD_LIMIT) { best[nb] = MM_NONE; idx[nb] = -1; }
+        if (second[nb] >= MM_PAD_LIMIT) second[nb] = MM_NONE;
+        const int ob = __shfl_xor(best[nb], 32, 64), oi = __shfl_xor(idx[nb], 32, 64), os = __shfl_xor(second[nb], 32, 64);
+        if (h == 0) {
+            if (ob < best[nb]) { second[nb] = min(best[nb], os); best[nb] = ob; idx[nb] = oi; }
+            const int s = s0 + nb * 32 + c;
+            if (s < n_src) part[(long long)blockIdx.y * n_src + s] = make_int4(best[nb], idx[nb], second[nb], 0);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void match_kernel(const DescriptorRec *__restrict__ src, int n_src, const DescriptorRec *__restrict__ tgt,
-                                                   int n_tgt, float abs_thr, float rel_thr, MatchRec *__restrict__ out /* [n_src] */) {
-    __shared__ int lds_t[MATCH_TILE * 33 + MATCH_TILE];
-    __shared__ int red_d[4][64], red_i[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int s = blockIdx.x * MATCH_SRC_PER_BLOCK + lane;
-    int a[32], na = 0;
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        a[k] = (s < n_src) ? (reinterpret_cast<const int *>(src[s].features)[k] ^ (int)0x80808080) : 0;
-        na = dot4(a[k], a[k], na);
+// splits combine in target order; thresholds as SIFTDescriptor.swift:349-355
+__global__ __launch_bounds__(256) void match_finalize_kernel(const int4 *__restrict__ part, int n_split, const int *__restrict__ src_norm, int n_src,
+                                                            float abs_thr, float rel_thr, MatchRec *__restrict__ out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_src) return;
+    int best = MM_NONE, idx = -1, second = MM_NONE;
+    for (int k = 0; k < n_split; k++) {
+        const int4 q = part[(long long)k * n_src + s];
+        if (q.x < best) { second = min(best, q.z); best = q.x; idx = q.y; }
     }
-    // ---- pass 1: global argmin (smallest index on ties)
-    int bd, bi;
-    match_pass<1>(tgt, n_tgt, a, na, 0, lds_t, bd, bi);
-    red_d[wv][lane] = bd; red_i[wv][lane] = bi;
-    __syncthreads();
-    int bestD = 0x7fffffff, bestI = -1;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const int d = red_d[w][lane], i = red_i[w][lane];
-        if (i >= 0 && (d < bestD || (d == bestD && i < bestI))) { bestD = d; bestI = i; }
+    MatchRec rec; rec.source = s; rec.target = -1; rec.distance = 0.0f;
+    if (idx >= 0) {
+        const int na = src_norm[s];
+        const float bd = sqrtf((float)(best + na)) / 255.0f;
+        const float sd = (second == MM_NONE) ? 3.402823466e+38f : sqrtf((float)(second + na)) / 255.0f;
+        rec.distance = bd;
+        if (bd < abs_thr && bd < sd * rel_thr) rec.target = idx;
     }
-    __syncthreads();
-    // ---- pass 2: minimum over the targets before the best one
-    int sd, si;
-    match_pass<2>(tgt, n_tgt, a, na, bestI, lds_t, sd, si);
-    red_d[wv][lane] = sd;
-    __syncthreads();
-    int secondD = 0x7fffffff;
-#pragma unroll
-    for (int w = 0; w < 4; w++) secondD = min(secondD, red_d[w][lane]);
-    if (wv != 0 || s >= n_src) return;
-    MatchRec r; r.source = s; r.target = -1; r.distance = 0.0f;
-    if (bestI >= 0) {
-        const float best = sqrtf((float)bestD) / 255.0f;
-        const float second = (secondD == 0x7fffffff) ? 3.402823466e+38f : sqrtf((float)secondD) / 255.0f;
-        r.distance = best;
-        if (best < abs_thr && best < second * rel_thr) r.target = bestI;      // SIFTDescriptor.swift:349-355
-    }
-    out[s] = r;
+    out[s] = rec;
 }
 
 }  // namespace siftmi

@@ -89,6 +89,7 @@ struct siftmi_ctx {
     std::vector<siftmi_match> h_matches;
     DescriptorRec *d_match_src = nullptr, *d_match_tgt = nullptr; long long match_src_cap = 0, match_tgt_cap = 0;
     MatchRec *d_match_out = nullptr; long long match_out_cap = 0;
+    int *d_match_scratch = nullptr; long long match_scratch_cap = 0;
     int last_frames = 0;                      // frames of the last batch call
     int last_sub_frames = 0;                  // frames resident in the pyramid
     bool pyramid_valid = false;
@@ -171,7 +172,7 @@ static void free_ctx(siftmi_ctx *c) {
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_ori_count, c->d_ori_angles,
                     c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_state, c->d_out_kp,
-                    c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out};
+                    c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out, c->d_match_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -829,10 +830,40 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
         HIP_TRY(hipMemcpyAsync(c->d_match_tgt, target, (size_t)n_target * sizeof(DescriptorRec), hipMemcpyHostToDevice, st));
         d_src = c->d_match_src; d_tgt = c->d_match_tgt;
     }
+    // target splits: enough blocks to fill 256 CUs twice over, each split a contiguous target range (multiple of 32)
+    const long long groups = (n_source + MM_SRC_PER_BLOCK - 1) / MM_SRC_PER_BLOCK;
+    // Target splits.  A CU holds 2 blocks, so 512 run at a time; blocks take equal time, so pick the split count (around
+    // 2048 blocks) whose last round is fullest.
+    long long split_len = 0;
+    {
+        const long long quanta = (n_target + MM_SPLIT_QUANTUM - 1) / MM_SPLIT_QUANTUM;
+        long long lo = (1024 + groups - 1) / groups, hi = (3072 + groups - 1) / groups;
+        double best_eff = -1.0;
+        for (long long k = lo; k <= hi; k++) {
+            long long q = (quanta + k - 1) / k;                       // quanta per split
+            if (q < 2) q = 2;
+            const long long ns = (quanta + q - 1) / q, blocks = ns * groups;
+            const double eff = (double)blocks / (double)((blocks + 511) / 512 * 512);
+            if (eff > best_eff + 1e-9) { best_eff = eff; split_len = q * MM_SPLIT_QUANTUM; }
+        }
+    }
+    const long long n_split = (n_target + split_len - 1) / split_len;
+    if (n_split > 65535) return set_error(SIFTMI_E_BADARG, "too many target splits");
+    // scratch: packed int8 rows + norms for both sides, per-split partial results (one allocation)
+    const long long words = n_source * 33 + n_target * 33 + n_split * n_source * 4 + 64;
+    if ((rc = grow((void **)&c->d_match_scratch, &c->match_scratch_cap, words, sizeof(int)))) return rc;
     if ((rc = grow((void **)&c->d_match_out, &c->match_out_cap, n_source, sizeof(MatchRec)))) return rc;
-    const int blocks = (int)((n_source + MATCH_SRC_PER_BLOCK - 1) / MATCH_SRC_PER_BLOCK);
-    hipLaunchKernelGGL(match_kernel, dim3(blocks), dim3(256), 0, st, d_src, (int)n_source, d_tgt, (int)n_target, absolute_threshold,
-                       relative_threshold, c->d_match_out);
+    int *src_packed = c->d_match_scratch;                               // 16-byte aligned pieces first
+    int *tgt_packed = src_packed + n_source * 32;
+    int4 *part = (int4 *)(tgt_packed + n_target * 32);
+    int *src_norm = (int *)(part + n_split * n_source);
+    int *tgt_norm = src_norm + n_source;
+    hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_source * 32 + 255) / 256)), dim3(256), 0, st, d_src, (int)n_source, src_packed, src_norm);
+    hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_target * 32 + 255) / 256)), dim3(256), 0, st, d_tgt, (int)n_target, tgt_packed, tgt_norm);
+    hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, (unsigned)n_split), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
+                       (int)n_target, (int)split_len, part);
+    hipLaunchKernelGGL(match_finalize_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, part, (int)n_split, src_norm, (int)n_source,
+                       absolute_threshold, relative_threshold, c->d_match_out);
     HIP_TRY(hipGetLastError());
     std::vector<siftmi_match> all((size_t)n_source);
     HIP_TRY(hipMemcpyAsync(all.data(), c->d_match_out, (size_t)n_source * sizeof(MatchRec), hipMemcpyDeviceToHost, st));

@@ -423,7 +423,7 @@ def _assert_matches_equal(got, want):
     np.testing.assert_allclose(got["distance"], want["distance"], rtol=3e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("n_src,n_tgt", [(1, 1), (5, 3), (64, 64), (65, 257), (300, 1000), (2500, 2300)])
+@pytest.mark.parametrize("n_src,n_tgt", [(1, 1), (5, 3), (64, 64), (65, 257), (300, 1000), (2500, 2300), (257, 33), (5000, 12000)])
 def test_match_random_vs_oracle(sm, n_src, n_tgt):
     from oracle import pyoracle
     rng = np.random.default_rng(100 + n_src)
