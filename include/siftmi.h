@@ -182,6 +182,19 @@ int siftmi_match_descriptors(siftmi_ctx *ctx, const siftmi_descriptor *source, i
                              float absolute_threshold, float relative_threshold,
                              const siftmi_match **matches, int64_t *count);
 
+/* SIFTDescriptor.matchGeometry(source:target:absoluteThreshold:relativeThreshold:) (SIFT/SIFTDescriptor.swift:104-144;
+   compareGeometry :162-296): match on the GPU, then the geometric-consistency score of the first 80 matches
+   (0 with fewer than 7 matches).  *_xy: the descriptors' keypoint absoluteCoordinate, [n][2] floats (x, y). */
+int siftmi_match_geometry(siftmi_ctx *ctx, const siftmi_descriptor *source, const float *source_xy, int64_t n_source,
+                          const siftmi_descriptor *target, const float *target_xy, int64_t n_target,
+                          float absolute_threshold, float relative_threshold, float *score, int64_t *n_matches);
+
+/* SIFTDescriptor.init's derived vectors (SIFT/SIFTDescriptor.swift:36-89), host memory, any output may be NULL:
+   raw_features [n][128] = features / 255; index_value [n][128] = the 16 cells re-ordered centre, corners, edges;
+   index_key [n][16] = the mean of each re-ordered cell. */
+int siftmi_descriptor_index(const siftmi_descriptor *descriptors, int64_t n, float *raw_features, float *index_value,
+                            float *index_key);
+
 /* --- record conversion (SIFTOctave.swift:470-489 host unpack) -------------------------------- */
 void siftmi_descriptor_to_reference(const siftmi_descriptor *in, int64_t n, siftmi_descriptor_reference *out);
 

@@ -79,6 +79,13 @@ def lib():
         L.so_num_threads.restype = C.c_int
         L.so_match.restype = C.c_int
         L.so_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int]
+        L.so_descriptor_index.restype = None
+        L.so_descriptor_index.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so_compare_geometry.restype = C.c_float
+        L.so_compare_geometry.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.so_match_geometry.restype = C.c_float
+        L.so_match_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                        C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -216,6 +223,30 @@ def match(src_features, tgt_features, absolute_threshold=1.176, relative_thresho
     out = np.zeros(max(len(a), 1), match_dtype)
     n = lib().so_match(_ptr(a), len(a), _ptr(b), len(b), absolute_threshold, relative_threshold, _ptr(out), len(out))
     return out[:n].copy()
+
+
+def descriptor_index(features):
+    """SIFTDescriptor.init's derived vectors: (rawFeatures [n,128], indexValue [n,128], indexKey [n,16])."""
+    f = np.ascontiguousarray(features, dtype=np.int32).reshape(-1, 128)
+    raw, val, key = np.zeros((len(f), 128), np.float32), np.zeros((len(f), 128), np.float32), np.zeros((len(f), 16), np.float32)
+    lib().so_descriptor_index(_ptr(f), len(f), _ptr(raw), _ptr(val), _ptr(key))
+    return raw, val, key
+
+
+def compare_geometry(matches, src_xy, tgt_xy, minimum_sample_size=7):
+    m = np.ascontiguousarray(matches, dtype=match_dtype)
+    a, b = np.ascontiguousarray(src_xy, dtype=np.float32), np.ascontiguousarray(tgt_xy, dtype=np.float32)
+    return float(lib().so_compare_geometry(_ptr(m), len(m), _ptr(a), _ptr(b), minimum_sample_size))
+
+
+def match_geometry(src_features, src_xy, tgt_features, tgt_xy, absolute_threshold=1.176, relative_threshold=0.6):
+    """SIFTDescriptor.matchGeometry -> (score, number of matches)."""
+    a = np.ascontiguousarray(src_features, dtype=np.int32)
+    b = np.ascontiguousarray(tgt_features, dtype=np.int32)
+    axy, bxy = np.ascontiguousarray(src_xy, dtype=np.float32), np.ascontiguousarray(tgt_xy, dtype=np.float32)
+    n = C.c_int(0)
+    s = lib().so_match_geometry(_ptr(a), _ptr(axy), len(a), _ptr(b), _ptr(bxy), len(b), absolute_threshold, relative_threshold, C.byref(n))
+    return float(s), n.value
 
 
 def num_threads():

@@ -838,3 +838,96 @@ int so_match(const int32_t *src /* [n_src][128] */, int n_src, const int32_t *tg
     free(res); free(traw);
     return count;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Sources/SIFTMetal/SIFT/SIFTDescriptor.swift:36-89  SIFTDescriptor.init: rawFeatures, indexValue, indexKey
+ *   rawFeatures[i] = Float(features[i]) / Float(255)                                   (:36-40)
+ *   the 128 values are cut into 16 runs of 8 (one run per 4x4 cell) and re-ordered centre cells 5,6,9,10,
+ *   corner cells 0,3,12,15, edge cells 1,2,4,7,8,11,13,14                              (:42-74)
+ *   indexValue = the re-ordered runs joined (128), indexKey = the mean of each run (16) (:78-88)
+ * mean is vDSP.mean (Utilities/Vector.swift:123-126), whose summation order is not documented; restated as
+ * a sequential f32 sum divided by 8.                                                                    */
+static const int so_index_cell_order[16] = {5, 6, 9, 10, 0, 3, 12, 15, 1, 2, 4, 7, 8, 11, 13, 14};
+
+void so_descriptor_index(const int32_t *features /* [n][128] */, int n, float *raw /* [n][128] */,
+                         float *indexValue /* [n][128] */, float *indexKey /* [n][16] */) {
+    for (int d = 0; d < n; d++) {
+        float r[SO_DESC_FEATURES];
+        for (int i = 0; i < SO_DESC_FEATURES; i++) r[i] = (float)features[(size_t)d * SO_DESC_FEATURES + i] / 255.0f;
+        if (raw) memcpy(raw + (size_t)d * SO_DESC_FEATURES, r, sizeof(r));
+        for (int k = 0; k < 16; k++) {
+            const float *run = r + so_index_cell_order[k] * 8;
+            float sum = 0.0f;
+            for (int i = 0; i < 8; i++) {
+                if (indexValue) indexValue[(size_t)d * SO_DESC_FEATURES + k * 8 + i] = run[i];
+                sum += run[i];
+            }
+            if (indexKey) indexKey[(size_t)d * 16 + k] = sum / 8.0f;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Sources/SIFTMetal/SIFT/SIFTDescriptor.swift:162-296  compareGeometry (private) on keypoint
+ * absoluteCoordinate pairs (makeCoordinate :146-160).  simd_length / simd_normalize / simd_dot are Apple
+ * <simd/geometry.h> inlines; restated as sqrtf(x*x + y*y), v * (1 / length), x0*y0 + x1*y1 in f32 -- their
+ * exact rounding is not pinned.                                                                         */
+static float so_clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+static float so_len2(float x, float y) { return sqrtf(x * x + y * y); }
+static float so_half_dot(float ax, float ay, float bx, float by) { return so_clamp01((ax * bx + ay * by) * 0.5f + 0.5f); } /* :158-160 */
+
+float so_compare_geometry(const so_match_rec *matches, int n, const float *src_xy, const float *tgt_xy, int minimumSampleSize) {
+    const float minimumLength = 2.0f;
+    float sum = 0.0f;
+    int count = 0;
+    float *scores = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n - 3; i++) {                                                    /* :173 */
+        const so_match_rec *m0 = &matches[i], *m1 = &matches[i + 1], *m2 = &matches[i + 2], *m3 = &matches[i + 3];
+        const float sbx = src_xy[2 * m1->source] - src_xy[2 * m0->source], sby = src_xy[2 * m1->source + 1] - src_xy[2 * m0->source + 1];
+        const float tbx = tgt_xy[2 * m1->target] - tgt_xy[2 * m0->target], tby = tgt_xy[2 * m1->target + 1] - tgt_xy[2 * m0->target + 1];
+        const float sbl = so_len2(sbx, sby), tbl = so_len2(tbx, tby);
+        if (!(sbl >= minimumLength)) continue;                                           /* :188-194 */
+        if (!(tbl >= minimumLength)) continue;
+        const float stx = src_xy[2 * m3->source] - src_xy[2 * m2->source], sty = src_xy[2 * m3->source + 1] - src_xy[2 * m2->source + 1];
+        const float ttx = tgt_xy[2 * m3->target] - tgt_xy[2 * m2->target], tty = tgt_xy[2 * m3->target + 1] - tgt_xy[2 * m2->target + 1];
+        const float stl = so_len2(stx, sty), ttl = so_len2(ttx, tty);
+        if (!(stl >= minimumLength)) continue;                                           /* :207-213 */
+        if (!(ttl >= minimumLength)) continue;
+        const float isb = 1.0f / sbl, itb = 1.0f / tbl, ist = 1.0f / stl, itt = 1.0f / ttl;
+        const float sourceRatio = stl / sbl, targetRatio = ttl / tbl;
+        const float sd = so_half_dot(stx * ist, sty * ist, sbx * isb, sby * isb);
+        const float td = so_half_dot(ttx * itt, tty * itt, tbx * itb, tby * itb);
+        const float orientationSimilarity = 1.0f - fabsf(sd - td);
+        const float scaleSimilarity = (sourceRatio < targetRatio) ? so_clamp01(sourceRatio / targetRatio) : so_clamp01(targetRatio / sourceRatio);
+        const float similarity = orientationSimilarity * scaleSimilarity;
+        const float score = similarity * similarity;
+        scores[count++] = score;
+        sum += score;
+    }
+    if (count < minimumSampleSize) { free(scores); return 0.0f; }                        /* :249-251 */
+    const float mean = sum / (float)count;
+    float error = 0.0f;
+    for (int i = 0; i < count; i++) { const float d = scores[i] - mean; error += d * d; }
+    const float variance = error / (float)(count - 1);
+    const float sd = sqrtf(variance);
+    float fairSum = 0.0f, fairCount = 0.0f;
+    for (int i = 0; i < count; i++) {
+        const float z = fabsf((scores[i] - mean) / sd);
+        if (z <= 2.0f) { fairSum += scores[i]; fairCount += 1.0f; }                      /* NaN z (sd == 0) fails the test, as in the reference */
+    }
+    free(scores);
+    return fairSum / fairCount;
+}
+
+/* Sources/SIFTMetal/SIFT/SIFTDescriptor.swift:104-144  matchGeometry: match, at least 7 matches, first 80 scored */
+float so_match_geometry(const int32_t *src, const float *src_xy, int n_src, const int32_t *tgt, const float *tgt_xy, int n_tgt,
+                        float absoluteThreshold, float relativeThreshold, int *n_matches) {
+    const int minimumSampleSize = 7, maximumSampleSize = 80;
+    so_match_rec *m = (so_match_rec *)malloc(sizeof(so_match_rec) * (size_t)(n_src > 0 ? n_src : 1));
+    const int n = so_match(src, n_src, tgt, n_tgt, absoluteThreshold, relativeThreshold, m, n_src);
+    if (n_matches) *n_matches = n;
+    float score = 0.0f;
+    if (n >= minimumSampleSize) score = so_compare_geometry(m, n < maximumSampleSize ? n : maximumSampleSize, src_xy, tgt_xy, minimumSampleSize);
+    free(m);
+    return score;
+}

@@ -112,6 +112,16 @@ typedef struct { int32_t source, target; float distance; } so_match_rec;
 int so_match(const int32_t *src, int n_src, const int32_t *tgt, int n_tgt, float absoluteThreshold, float relativeThreshold,
              so_match_rec *out, int cap);
 
+/* SIFTDescriptor.init (SIFT/SIFTDescriptor.swift:36-89): rawFeatures [n][128], indexValue [n][128], indexKey [n][16];
+   any output may be NULL */
+void so_descriptor_index(const int32_t *features, int n, float *raw, float *indexValue, float *indexKey);
+
+/* compareGeometry (SIFT/SIFTDescriptor.swift:162-296) over matches whose source/target index rows of xy pairs, and
+   matchGeometry (:104-144) = match + compareGeometry on the first 80 matches */
+float so_compare_geometry(const so_match_rec *matches, int n, const float *src_xy, const float *tgt_xy, int minimumSampleSize);
+float so_match_geometry(const int32_t *src, const float *src_xy, int n_src, const int32_t *tgt, const float *tgt_xy, int n_tgt,
+                        float absoluteThreshold, float relativeThreshold, int *n_matches);
+
 int so_num_threads(void);
 
 #ifdef __cplusplus

@@ -41,16 +41,31 @@ class SIFTKeypoint:                      # SIFT/SIFTKeypoint.swift:11-57
     value: float
 
 
+def _index_vectors(features):
+    """rawFeatures, indexValue, indexKey of [n,128] integer features through siftmi_descriptor_index."""
+    rec = np.zeros(len(features), descriptor_dtype)
+    if len(features):
+        rec["features"] = features
+    raw, val, key = (np.zeros((len(rec), 128), np.float32), np.zeros((len(rec), 128), np.float32), np.zeros((len(rec), 16), np.float32))
+    _capi.check(_capi.load().siftmi_descriptor_index(rec.ctypes.data, len(rec), raw.ctypes.data, val.ctypes.data, key.ctypes.data))
+    return raw, val, key
+
+
 @dataclass
-class SIFTDescriptor:                    # SIFT/SIFTDescriptor.swift:12-40
+class SIFTDescriptor:                    # SIFT/SIFTDescriptor.swift:12-89
     keypoint: SIFTKeypoint
     theta: float
     features: List[int]                  # 128 integers 0...255 (IntVector)
-    rawFeatures: List[float] = field(default_factory=list)   # features / 255 (FloatVector), :36-40
+    rawFeatures: List[float] = field(default_factory=list, repr=False)   # features / 255 (FloatVector), :36-40
+    indexValue: List[float] = field(default_factory=list, repr=False)    # cells re-ordered centre, corners, edges, :42-81 (private there)
+    indexKey: List[float] = field(default_factory=list, repr=False)      # mean of each re-ordered cell, :83-87 (private there)
 
     def __post_init__(self):
-        if not self.rawFeatures:
-            self.rawFeatures = [np.float32(f) / np.float32(255) for f in self.features]
+        if len(self.features) == 0:      # precondition(features.count > 0), :31
+            raise ValueError("features must not be empty")
+        if len(self.rawFeatures) == 0 or len(self.indexValue) == 0 or len(self.indexKey) == 0:
+            raw, val, key = _index_vectors(np.asarray(self.features, dtype=np.int64).reshape(1, 128))
+            self.rawFeatures, self.indexValue, self.indexKey = raw[0], val[0], key[0]
 
 
 @dataclass
@@ -167,6 +182,18 @@ class Engine:
             return np.zeros(0, _capi.match_dtype)
         return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 12,)).view(_capi.match_dtype).copy()
 
+    def match_geometry(self, source, source_xy, target, target_xy, absolute_threshold=1.176, relative_threshold=0.6):
+        """SIFTDescriptor.matchGeometry on descriptor records + [n,2] (x, y) absolute coordinates -> (score, n_matches)."""
+        a = np.ascontiguousarray(source, dtype=descriptor_dtype)
+        b = np.ascontiguousarray(target, dtype=descriptor_dtype)
+        axy = np.ascontiguousarray(source_xy, dtype=np.float32)
+        bxy = np.ascontiguousarray(target_xy, dtype=np.float32)
+        assert axy.shape == (len(a), 2) and bxy.shape == (len(b), 2)
+        score, n = C.c_float(), C.c_int64()
+        _capi.check(self.L.siftmi_match_geometry(self.h, a.ctypes.data, axy.ctypes.data, len(a), b.ctypes.data, bxy.ctypes.data, len(b),
+                                                 absolute_threshold, relative_threshold, C.byref(score), C.byref(n)))
+        return float(score.value), int(n.value)
+
     # ---- introspection ----
     def stats(self):
         s = _capi.Stats()
@@ -273,23 +300,35 @@ class SIFT:
         ds, dc = self._engine.describe(flat, counts)
         out, pos = [], 0
         for o in range(self._engine.n_octaves):
-            out.append([SIFTDescriptor(keypointOctaves[o][int(r["keypoint"])], float(r["theta"]), r["features"].astype(int).tolist())
-                        for r in ds[pos:pos + dc[o]]])
+            rows = ds[pos:pos + dc[o]]
+            raw, val, key = _index_vectors(rows["features"])
+            out.append([SIFTDescriptor(keypointOctaves[o][int(r["keypoint"])], float(r["theta"]), r["features"].astype(int).tolist(),
+                                       raw[i], val[i], key[i]) for i, r in enumerate(rows)])
             pos += dc[o]
+        return out
+
+    @staticmethod
+    def _pack(ds):
+        out = np.zeros(len(ds), descriptor_dtype)
+        for i, d in enumerate(ds):
+            out[i]["theta"] = d.theta
+            out[i]["features"] = d.features
         return out
 
     def match(self, source: List[SIFTDescriptor], target: List[SIFTDescriptor], absoluteThreshold: float = 1.176,
               relativeThreshold: float = 0.6) -> List["SIFTCorrespondence"]:
         """SIFTDescriptor.match(source:target:absoluteThreshold:relativeThreshold:) (SIFTDescriptor.swift:298-318);
         a static function in the reference, hosted on the SIFT object here because it needs the device context."""
-        def pack(ds):
-            out = np.zeros(len(ds), descriptor_dtype)
-            for i, d in enumerate(ds):
-                out[i]["theta"] = d.theta
-                out[i]["features"] = d.features
-            return out
-        m = self._engine.match(pack(source), pack(target), absoluteThreshold, relativeThreshold)
+        m = self._engine.match(self._pack(source), self._pack(target), absoluteThreshold, relativeThreshold)
         return [SIFTCorrespondence(source[int(r["source"])], target[int(r["target"])], float(r["distance"])) for r in m]
+
+    def matchGeometry(self, source: List[SIFTDescriptor], target: List[SIFTDescriptor], absoluteThreshold: float = 1.176,
+                      relativeThreshold: float = 0.6) -> float:
+        """SIFTDescriptor.matchGeometry(source:target:absoluteThreshold:relativeThreshold:) (SIFTDescriptor.swift:104-144)."""
+        a, b = self._pack(source), self._pack(target)
+        axy = np.array([d.keypoint.absoluteCoordinate for d in source], np.float32).reshape(-1, 2)
+        bxy = np.array([d.keypoint.absoluteCoordinate for d in target], np.float32).reshape(-1, 2)
+        return self._engine.match_geometry(a, axy, b, bxy, absoluteThreshold, relativeThreshold)[0]
 
     # BASELINE.json's north_star names the API detect()/describe(); keep them as aliases.
     detect = getKeypoints

@@ -24,6 +24,7 @@
 #include "dense_kernels.hip.h"
 #include "keypoint_kernels.hip.h"
 #include "match_kernels.hip.h"
+#include "host_post.h"
 
 using namespace siftmi;
 
@@ -872,6 +873,32 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
         if (m.target >= 0) c->h_matches.push_back(m);                        // source order (:304-314)
     *count = (int64_t)c->h_matches.size();
     if (matches) *matches = c->h_matches.data();
+    return SIFTMI_OK;
+}
+
+// SIFTDescriptor.matchGeometry (SIFT/SIFTDescriptor.swift:104-144)
+extern "C" int siftmi_match_geometry(siftmi_ctx *c, const siftmi_descriptor *source, const float *source_xy, int64_t n_source,
+                                     const siftmi_descriptor *target, const float *target_xy, int64_t n_target, float absolute_threshold,
+                                     float relative_threshold, float *score, int64_t *n_matches) {
+    if (!score || (n_source > 0 && !source_xy) || (n_target > 0 && !target_xy)) return set_error(SIFTMI_E_BADARG, "bad argument");
+    const siftmi_match *m = nullptr;
+    int64_t n = 0;
+    const int rc = siftmi_match_descriptors(c, source, n_source, target, n_target, 0, absolute_threshold, relative_threshold, &m, &n);
+    if (rc != SIFTMI_OK) return rc;
+    if (n_matches) *n_matches = n;
+    const int minimum_sample_size = 7, maximum_sample_size = 80;                           // :113-114
+    *score = 0.0f;
+    if (n >= minimum_sample_size)
+        *score = compare_geometry(m, (int)(n < maximum_sample_size ? n : maximum_sample_size), source_xy, target_xy, minimum_sample_size);
+    return SIFTMI_OK;
+}
+
+// SIFTDescriptor.init derived vectors (SIFT/SIFTDescriptor.swift:36-89)
+extern "C" int siftmi_descriptor_index(const siftmi_descriptor *d, int64_t n, float *raw_features, float *index_value, float *index_key) {
+    if (n < 0 || (n > 0 && !d)) return set_error(SIFTMI_E_BADARG, "bad argument");
+    for (int64_t i = 0; i < n; i++)
+        descriptor_index_vectors(d[i], raw_features ? raw_features + i * 128 : nullptr, index_value ? index_value + i * 128 : nullptr,
+                                 index_key ? index_key + i * 16 : nullptr);
     return SIFTMI_OK;
 }
 

@@ -57,6 +57,14 @@ def main():
             assert im.shape == (680, 1024), im.shape
             st = 2 ** o
             out["scalespace_o%d_s%d" % (o, s)] = np.ascontiguousarray(im[::st, ::st]).astype(np.uint8)
+    # wire-format sample: the first 8 lines of the descriptor file and of one keypoint file, verbatim (data, text form)
+    for name, dst in [("butterfly-descriptors.txt", "butterfly-descriptors-head.txt"),
+                      ("extra_OnEdgeResp_butterfly.txt", "butterfly-keypoints-head.txt")]:
+        with open(os.path.join(SRC, name)) as f, open(os.path.join(DST, dst), "w") as g:
+            for i, line in enumerate(f):
+                if i == 8:
+                    break
+                g.write(line)
     np.savez_compressed(os.path.join(DST, "butterfly_ipol.npz"), **out)
     print("wrote", {k: v.shape for k, v in out.items() if not k.startswith("scalespace")})
 

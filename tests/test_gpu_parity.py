@@ -494,3 +494,57 @@ def test_match_real_frames_through_reference_api(sm):
     assert len(got) > 100
     ok = (np.abs(dx - 3) < 1.0) & (np.abs(dy - 3) < 1.0)
     assert ok.mean() > 0.9
+
+
+def test_match_geometry_vs_oracle(sm):
+    """SIFTDescriptor.matchGeometry: GPU match + host score against the oracle's flow on the same inputs."""
+    from oracle import pyoracle
+    rng = np.random.default_rng(21)
+    tgt = _sift_like(rng, 400)
+    src = np.clip(tgt[:260] + rng.integers(-6, 7, (260, 128)), 0, 255).astype(np.int32)
+    sxy = rng.uniform(0, 900, (260, 2)).astype(np.float32)
+    th = 0.3
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]], np.float32) * np.float32(0.8)
+    txy = np.concatenate([(sxy @ R.T + rng.normal(0, 0.4, sxy.shape)).astype(np.float32), rng.uniform(0, 900, (140, 2)).astype(np.float32)])
+    eng = sm.Engine(64, 64, n_octaves=1)
+    for case_txy in (txy, rng.uniform(0, 900, txy.shape).astype(np.float32)):
+        score, n = eng.match_geometry(_records(sm, src), sxy, _records(sm, tgt), case_txy)
+        want, wn = pyoracle.match_geometry(src, sxy, tgt, case_txy)
+        assert n == wn and n >= 80
+        assert score == pytest.approx(want, rel=1e-6)        # TOL: identical matches -> identical f32 operations; 1e-6 covers libm sqrtf
+    assert eng.match_geometry(_records(sm, src[:4]), sxy[:4], _records(sm, tgt), txy) == (0.0, pyoracle.match_geometry(src[:4], sxy[:4], tgt, txy)[1])
+    eng.close()
+
+
+def test_reference_testMatches_flow_on_butterfly(sm, butterfly_bgra, ipol):
+    """The reference's DescriptorTests.testMatches: descriptors found on butterfly.png are matched against IPOL's
+    butterfly-descriptors.txt with absoluteThreshold 300, relativeThreshold 0.6.  The reference only draws the
+    result; here the matches must equal the oracle matcher's on the same two lists, and the derived vectors of the
+    reference-side objects must equal the oracle's."""
+    from oracle import pyoracle
+    from siftmetal_amd import wire
+    h, w = butterfly_bgra.shape[:2]
+    sift = sm.SIFT(device=0, configuration=sm.SIFT.Configuration(inputSize=sm.IntegralSize(w, h)))
+    found = [d for o in sift.getDescriptors(sift.getKeypoints(butterfly_bgra)) for d in o]
+    text = "".join("%f %f %f %f %s \n" % (y, x, s, t, " ".join(str(int(v)) for v in f))
+                   for (y, x, s, t), f in zip(ipol["desc_yxst"], ipol["desc_features"]))
+    reference = wire.parseDescriptors(text)
+    assert len(reference) == 1609 and len(found) == 1420          # 802 + 466 + 125 + 23 + 4, the per-octave counts pinned in test_oracle_golden
+    got = sift.match(found, reference, absoluteThreshold=300, relativeThreshold=0.6)
+    want = pyoracle.match(np.array([d.features for d in found]), ipol["desc_features"].astype(np.int32), 300, 0.6)
+    assert [id(m.source) for m in got] == [id(found[int(r["source"])]) for r in want]
+    assert [id(m.target) for m in got] == [id(reference[int(r["target"])]) for r in want]
+    np.testing.assert_allclose([m.featureDistance for m in got], want["distance"], rtol=3e-6, atol=1e-7)
+    # OpenSIFT-style descriptors against IPOL's: a real but partial overlap (the reference's own 80 % check is dead code)
+    assert len(got) > 50
+    near = [np.hypot(m.source.keypoint.absoluteCoordinate[0] - m.target.keypoint.absoluteCoordinate[0],
+                     m.source.keypoint.absoluteCoordinate[1] - m.target.keypoint.absoluteCoordinate[1]) < 3.0 for m in got]
+    assert np.mean(near) > 0.8
+    raw, val, key = pyoracle.descriptor_index(np.array([d.features for d in found[:64]]))
+    np.testing.assert_array_equal(np.array([d.indexValue for d in found[:64]]), val)
+    np.testing.assert_array_equal(np.array([d.indexKey for d in found[:64]]), key)
+    score = sift.matchGeometry(found, reference, absoluteThreshold=300, relativeThreshold=0.6)
+    want_score, _ = pyoracle.match_geometry(np.array([d.features for d in found]), np.array([d.keypoint.absoluteCoordinate for d in found], np.float32),
+                                            ipol["desc_features"].astype(np.int32),
+                                            np.array([d.keypoint.absoluteCoordinate for d in reference], np.float32), 300, 0.6)
+    assert score == pytest.approx(want_score, rel=1e-6, nan_ok=True)
