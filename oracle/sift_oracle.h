@@ -107,6 +107,9 @@ int so_detect_describe(so_ctx *c, const void *pixels, int format, int row_stride
                        int32_t *n_extrema, int32_t *n_keypoints, int32_t *n_oriented,
                        int32_t *n_descriptors);
 
+/* ---- rows after describe.  PARITY UNPINNED for everything below: the reference's tests hold no expected
+   outputs for match / matchGeometry / the derived vectors, and Apple's vDSP / simd roundings are undocumented; these
+   restatements follow the cited lines and are cross-checked by literal Python restatements in tests/. ---- */
 /* SIFTDescriptor.match (SIFT/SIFTDescriptor.swift:298-361): brute force + ratio test, matches in source order */
 typedef struct { int32_t source, target; float distance; } so_match_rec;
 int so_match(const int32_t *src, int n_src, const int32_t *tgt, int n_tgt, float absoluteThreshold, float relativeThreshold,
