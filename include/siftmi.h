@@ -171,6 +171,13 @@ int siftmi_detect_describe_batch_device(siftmi_ctx *ctx, int32_t n_frames, const
                                         siftmi_descriptor *d_descriptors, int64_t desc_capacity,
                                         int32_t *d_counts, int32_t *d_totals, void *stream);
 
+/* Pinned (page-locked) host memory for frames fed from the host.  The reference hands the GPU an MTLTexture in unified
+   memory; on a discrete GPU the frames cross PCIe, and copies from pinned memory are asynchronous and roughly twice as
+   fast as from pageable memory.  The batch entry points overlap the copy of one sub-batch with the kernels of the
+   previous one either way. */
+int siftmi_host_alloc(size_t bytes, void **ptr);
+int siftmi_host_free(void *ptr);
+
 /* --- next row: SIFTDescriptor.match(source:target:absoluteThreshold:relativeThreshold:)
    (SIFT/SIFTDescriptor.swift:298-361), brute force + ratio test.  siftmi_match replaces
    SIFTCorrespondence (SIFT/SIFTCorrespondence.swift:11-16) with indices into the two input lists.

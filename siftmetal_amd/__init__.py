@@ -85,6 +85,40 @@ def _fmt_of(img):
     raise ValueError("image must be HxWx4 uint8 (BGRA, the reference's .bgra8Unorm), HxW uint8 or HxW float32")
 
 
+class _PinnedBuffer:
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        _capi.check(_capi.load().siftmi_host_alloc(nbytes, C.byref(self.ptr)))
+        self.nbytes = nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _capi.load().siftmi_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array over page-locked host memory (siftmi_host_alloc): frames stored here cross PCIe asynchronously at
+    the full link rate when passed to the batch API.  The memory lives as long as the array (and its views)."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    buf = _PinnedBuffer(max(n, 1))
+    arr = np.ctypeslib.as_array(C.cast(buf.ptr, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].view(dtype).reshape(shape)
+    _pinned_owner[arr.ctypes.data] = buf     # keep-alive keyed by address; dropped by pinned_release or at exit
+    return arr
+
+
+_pinned_owner = {}
+
+
+def pinned_release(arr):
+    """Free a pinned_empty array's memory now (the array must not be used afterwards)."""
+    _pinned_owner.pop(arr.ctypes.data, None)
+
+
 class Engine:
     """Array-level access to one siftmi context (used by tests, bench.py and the stream driver)."""
 
@@ -149,8 +183,9 @@ class Engine:
         d = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 136,))[:n * 136].view(descriptor_dtype).copy()
         return d, dc
 
-    def detect_describe_batch(self, frames, allow_capacity=False):
-        """frames: [n, H, W(,4)] array.  Returns (keypoints, kp_counts[n, n_oct], descriptors, desc_counts[n, n_oct])."""
+    def detect_describe_batch(self, frames, allow_capacity=False, copy=True):
+        """frames: [n, H, W(,4)] array.  Returns (keypoints, kp_counts[n, n_oct], descriptors, desc_counts[n, n_oct]).
+        copy=False returns views of the context's pinned result buffers, valid until the next call (the C ABI's contract)."""
         frames = np.ascontiguousarray(frames)
         n = frames.shape[0]
         fmt = _fmt_of(frames[0])
@@ -160,8 +195,10 @@ class Engine:
         kc = np.ctypeslib.as_array(C.cast(pkc, C.POINTER(C.c_int32)), shape=(n, self.n_octaves)).copy()
         dc = np.ctypeslib.as_array(C.cast(pdc, C.POINTER(C.c_int32)), shape=(n, self.n_octaves)).copy()
         nk, nd = int(kc.sum()), int(dc.sum())
-        kps = np.ctypeslib.as_array(C.cast(pk, C.POINTER(C.c_uint8)), shape=(max(nk, 1) * 44,))[:nk * 44].view(keypoint_dtype).copy()
-        ds = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_uint8)), shape=(max(nd, 1) * 136,))[:nd * 136].view(descriptor_dtype).copy()
+        kps = np.ctypeslib.as_array(C.cast(pk, C.POINTER(C.c_uint8)), shape=(max(nk, 1) * 44,))[:nk * 44].view(keypoint_dtype)
+        ds = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_uint8)), shape=(max(nd, 1) * 136,))[:nd * 136].view(descriptor_dtype)
+        if copy:
+            kps, ds = kps.copy(), ds.copy()
         return kps, kc, ds, dc
 
     def detect_describe_batch_device(self, n_frames, d_pixels, fmt, row_stride, frame_stride, d_kp, kp_cap, d_desc, desc_cap,

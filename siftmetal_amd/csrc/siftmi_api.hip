@@ -66,8 +66,11 @@ struct siftmi_ctx {
     // device memory
     float *d_gauss = nullptr;
     size_t frame_stride = 0;                  // floats
-    unsigned char *d_input = nullptr;         // staging for host frames
-    size_t input_bytes = 0;
+    unsigned char *d_input = nullptr;         // staging for host frames: two slots of B frames, filled on copy_stream
+    size_t input_bytes = 0;                   //   while the previous sub-batch computes
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    int input_slot = 0;
     ExtremumRec *d_ext = nullptr;
     KeypointRec *d_kp_tmp = nullptr, *d_kp = nullptr;
     unsigned long long *d_keys = nullptr;
@@ -84,8 +87,23 @@ struct siftmi_ctx {
     DescriptorRec *d_out_desc = nullptr; long long out_desc_cap = 0;
     int32_t *d_out_counts = nullptr, *d_stats = nullptr; int out_frames_cap = 0;
     // host mirrors
-    std::vector<siftmi_keypoint> h_kp;
-    std::vector<siftmi_descriptor> h_desc;
+    // host result buffers: pinned, grown geometrically, never zero-filled (std::vector::resize would touch every byte)
+    template <typename T> struct PinnedBuf {
+        T *p = nullptr; size_t cap = 0;
+        T *data() const { return p; }
+        hipError_t resize(size_t n) {
+            if (n <= cap) return hipSuccess;
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = n + n / 2;
+            hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+            if (e == hipSuccess) cap = want;
+            return e;
+        }
+        void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    };
+    PinnedBuf<siftmi_keypoint> h_kp;
+    PinnedBuf<siftmi_descriptor> h_desc;
     std::vector<int32_t> h_counts, h_stats;
     std::vector<siftmi_match> h_matches;
     DescriptorRec *d_match_src = nullptr, *d_match_tgt = nullptr; long long match_src_cap = 0, match_tgt_cap = 0;
@@ -183,6 +201,12 @@ static void free_ctx(siftmi_ctx *c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->oct_stream[i]) (void)hipStreamDestroy(c->oct_stream[i]);
     }
+    c->h_kp.release(); c->h_desc.release();
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -268,11 +292,16 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
 
     hipError_t e = hipSetDevice(hip_device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2; i++) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming);
+    }
     const size_t B = (size_t)c->B, G = B * c->n_oct;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 16)); };
     alloc((void **)&c->d_gauss, B * off * sizeof(float));
     c->input_bytes = (size_t)W * H * 4;
-    alloc((void **)&c->d_input, B * c->input_bytes);
+    alloc((void **)&c->d_input, 2 * B * c->input_bytes);
     alloc((void **)&c->d_ext, B * ext_off * sizeof(ExtremumRec));
     alloc((void **)&c->d_kp_tmp, B * kp_off * sizeof(KeypointRec));
     alloc((void **)&c->d_kp, B * kp_off * sizeof(KeypointRec));
@@ -637,17 +666,51 @@ static int overflow_error(siftmi_ctx *c, int flags) {
 }
 
 // stage frames from the host (or accept a device pointer) and return the device view
+// Host frames go to one of two staging slots on the copy stream; the compute stream waits for the slot's copy, and the
+// copy of the next sub-batch waits until the compute stream has consumed the slot (input_consumed).  The H2D copy of
+// sub-batch i+1 therefore overlaps the kernels of sub-batch i.
 static int stage_input(siftmi_ctx *c, int nf, const void *pixels, int format, size_t row_stride, size_t frame_stride, int on_device,
                        const void **d_px, size_t *d_row, size_t *d_frame) {
     if (on_device) { *d_px = pixels; *d_row = row_stride; *d_frame = frame_stride; return SIFTMI_OK; }
     const size_t bpp = format == SIFTMI_FMT_GRAY8 ? 1 : 4;
     const size_t row = bpp * (size_t)c->cfg.width;
-    const size_t fr = row * c->cfg.height;
-    for (int f = 0; f < nf; f++)
-        HIP_TRY(hipMemcpy2DAsync(c->d_input + (size_t)f * c->input_bytes, row, (const unsigned char *)pixels + (size_t)f * frame_stride,
-                                 row_stride, row, c->cfg.height, hipMemcpyHostToDevice, c->stream));
-    (void)fr;
-    *d_px = c->d_input; *d_row = row; *d_frame = c->input_bytes;
+    const int slot = c->input_slot;
+    unsigned char *dst = c->d_input + (size_t)slot * c->B * c->input_bytes;
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_consumed[slot], 0));
+    if (row_stride == row && frame_stride == row * (size_t)c->cfg.height && c->input_bytes == frame_stride) {
+        HIP_TRY(hipMemcpyAsync(dst, pixels, (size_t)nf * frame_stride, hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+        for (int f = 0; f < nf; f++)
+            HIP_TRY(hipMemcpy2DAsync(dst + (size_t)f * c->input_bytes, row, (const unsigned char *)pixels + (size_t)f * frame_stride, row_stride, row,
+                                     c->cfg.height, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    HIP_TRY(hipEventRecord(c->ev_copied[slot], c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_copied[slot], 0));
+    *d_px = dst; *d_row = row; *d_frame = c->input_bytes;
+    return SIFTMI_OK;
+}
+
+// called after the kernels that read the staged frames have been enqueued on the compute stream
+static int input_consumed(siftmi_ctx *c, int on_device) {
+    if (on_device) return SIFTMI_OK;
+    HIP_TRY(hipEventRecord(c->ev_consumed[c->input_slot], c->stream));
+    c->input_slot ^= 1;
+    return SIFTMI_OK;
+}
+
+// Pinned host memory for callers that feed frames from the host: H2D copies from it are asynchronous and run at the
+// full PCIe rate (pageable memory is staged through the runtime's bounce buffers at roughly half that).
+extern "C" int siftmi_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return set_error(SIFTMI_E_BADARG, "null argument");
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? SIFTMI_E_NOMEM : SIFTMI_E_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_host_free(void *ptr) {
+    if (!ptr) return SIFTMI_OK;
+    HIP_TRY(hipHostFree(ptr));
     return SIFTMI_OK;
 }
 
@@ -674,6 +737,7 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
         const unsigned char *src = (const unsigned char *)pixels + (size_t)f0 * frame_stride;
         if ((rc = stage_input(c, nf, src, format, row_stride, frame_stride, on_device, &d_px, &d_row, &d_frame))) return rc;
         if ((rc = run_dense_detect(c, st, nf, d_px, format, d_row, d_frame, false))) return rc;
+        if ((rc = input_consumed(c, on_device))) return rc;
         if ((rc = run_refine(c, st, nf))) return rc;
         if ((rc = run_describe(c, st, nf))) return rc;
         if ((rc = run_pack(c, st, nf, f0, n_frames, c->d_out_kp, c->out_kp_cap, c->d_out_desc, c->out_desc_cap, c->d_out_counts, c->d_stats)))
@@ -687,7 +751,7 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     HIP_TRY(hipMemcpyAsync(c->h_counts.data(), c->d_out_counts, 2 * ng * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(c->h_stats.data(), c->d_stats, 5 * ng * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    c->h_kp.resize((size_t)std::max(ps.total_kp, 1)); c->h_desc.resize((size_t)std::max(ps.total_desc, 1));
+    HIP_TRY(c->h_kp.resize((size_t)std::max(ps.total_kp, 1))); HIP_TRY(c->h_desc.resize((size_t)std::max(ps.total_desc, 1)));
     if (ps.total_kp) HIP_TRY(hipMemcpyAsync(c->h_kp.data(), c->d_out_kp, (size_t)ps.total_kp * sizeof(KeypointRec), hipMemcpyDeviceToHost, st));
     if (ps.total_desc) HIP_TRY(hipMemcpyAsync(c->h_desc.data(), c->d_out_desc, (size_t)ps.total_desc * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -714,6 +778,7 @@ extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size
     const void *d_px; size_t d_row, d_frame;
     if ((rc = stage_input(c, 1, pixels, format, row_stride, 0, on_device, &d_px, &d_row, &d_frame))) return rc;
     if ((rc = run_dense_detect(c, st, 1, d_px, format, d_row, d_frame, false))) return rc;
+    if ((rc = input_consumed(c, on_device))) return rc;
     if ((rc = run_refine(c, st, 1))) return rc;
     std::vector<int32_t> h(5 * (size_t)c->B * c->n_oct);
     HIP_TRY(hipMemcpyAsync(h.data(), c->d_counters, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -730,7 +795,7 @@ extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size
         total += nk;
         for (int k = 0; k < 3; k++) c->h_stats[(size_t)k * c->n_oct + o] = h[k * cs + o];
     }
-    c->h_kp.resize(std::max<size_t>(total, 1));
+    HIP_TRY(c->h_kp.resize(std::max<size_t>(total, 1)));
     size_t pos = 0;
     for (int o = 0; o < c->n_oct; o++) {
         if (counts[o]) HIP_TRY(hipMemcpyAsync(c->h_kp.data() + pos, c->d_kp + c->P.kp_off[o], (size_t)counts[o] * sizeof(KeypointRec), hipMemcpyDeviceToHost, st));
@@ -787,7 +852,7 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
         c->h_stats[(size_t)3 * c->n_oct + o] = hc[C_ORIENTED * cs + o];
         c->h_stats[(size_t)4 * c->n_oct + o] = hc[C_DESC * cs + o];
     }
-    c->h_desc.resize(std::max<size_t>(total, 1));
+    HIP_TRY(c->h_desc.resize(std::max<size_t>(total, 1)));
     pos = 0;
     for (int o = 0; o < c->n_oct; o++) {
         if (desc_counts[o]) HIP_TRY(hipMemcpyAsync(c->h_desc.data() + pos, c->d_desc + c->P.desc_off[o], (size_t)desc_counts[o] * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
