@@ -51,6 +51,7 @@ struct PyramidDesc {
     int32_t cap_ext[MAX_OCT], cap_kp[MAX_OCT], cap_desc[MAX_OCT];
     size_t ext_off[MAX_OCT], kp_off[MAX_OCT], desc_off[MAX_OCT];   // element offsets of the octave's segment inside a frame's segment
     size_t ext_frame, kp_frame, desc_frame;                        // elements per frame
+    size_t row_off[MAX_OCT], row_frame;                            // keypoint sort: (nspo + 2) * h row buckets per octave
 };
 
 struct DetectParams {              // SIFTInterpolateParameters (SIFTInterpolate.h:14-23) + literals
@@ -270,7 +271,7 @@ __device__ __forceinline__ bool out_of_bounds(int x, int y, int s, int w, int h,
 __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams prm,
                                                     const ExtremumRec *__restrict__ lists, const int32_t *__restrict__ cand_count,
                                                     KeypointRec *__restrict__ kp_tmp, unsigned long long *__restrict__ kp_keys,
-                                                    int32_t *__restrict__ kp_count) {
+                                                    int32_t *__restrict__ kp_count, int32_t *__restrict__ row_count) {
     __shared__ int s_n, s_base;
     const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(cand_count[group], P.cap_ext[o]);
@@ -341,33 +342,81 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
             const size_t slot = (size_t)frame * P.kp_frame + P.kp_off[o] + s_base + li;
             kp_tmp[slot] = r;
             kp_keys[slot] = key;
+            atomicAdd(&row_count[(size_t)frame * P.row_frame + P.row_off[o] + (size_t)(r.scale * h + r.y)], 1);   // bucket sizes for the sort
         }
         __syncthreads();
     }
 }
 
-// Rank sort per (frame, octave) group: deterministic order (scale, y, x, then originating
-// extremum) for lists whose append order came from atomics.  O(n^2) compares, n is a few
-// thousand; keys are unique.
-__global__ __launch_bounds__(256) void sort_keypoints_kernel(PyramidDesc P, const KeypointRec *__restrict__ kp_tmp,
-                                                            const unsigned long long *__restrict__ kp_keys,
-                                                            const int32_t *__restrict__ kp_count, KeypointRec *__restrict__ kp_sorted) {
-    __shared__ unsigned long long tile[1024];
+// Keypoint sort per (frame, octave) group: deterministic order (scale, y, x, then originating extremum) for lists
+// whose append order came from atomics; keys are unique.  Bucket sort by pyramid row (scale, y): refine_kernel counted
+// the keypoints per row; kp_row_scan_kernel turns the counts into bucket starts; kp_row_scatter_kernel drops (key,
+// source index) into the buckets in arbitrary order; kp_row_rank_kernel ranks every entry inside its bucket (a row holds
+// a handful of keypoints) and moves the record.  O(n + rows) instead of the O(n^2) of a plain rank sort, which took
+// 3.9 ms of a 13 ms 8192 x 8192 tile (50 k keypoints in one group).
+__global__ __launch_bounds__(1024) void kp_row_scan_kernel(PyramidDesc P, int32_t *__restrict__ row_count /* in: counts, out: zeros */,
+                                                          int32_t *__restrict__ row_start) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int group = blockIdx.x, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n_rows = (P.nspo + 2) * P.h[o];
+    const size_t base = (size_t)frame * P.row_frame + P.row_off[o];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n_rows; r0 += 1024) {
+        const int r = r0 + threadIdx.x;
+        const int v = (r < n_rows) ? row_count[base + r] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; k++) woff += wsum[k];
+        const int c0 = carry;
+        if (r < n_rows) { row_start[base + r] = c0 + woff + incl - v; row_count[base + r] = 0; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c0 + woff + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void kp_row_scatter_kernel(PyramidDesc P, const unsigned long long *__restrict__ kp_keys,
+                                                            const int32_t *__restrict__ kp_count, const int32_t *__restrict__ row_start,
+                                                            int32_t *__restrict__ row_fill, unsigned long long *__restrict__ bucket_keys,
+                                                            int32_t *__restrict__ bucket_src) {
     const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
-    const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-        const int i = i0 + threadIdx.x;
-        const unsigned long long key = (i < n) ? kp_keys[base + i] : ~0ull;
-        int rank = 0;
-        for (int j0 = 0; j0 < n; j0 += 1024) {
-            __syncthreads();
-            for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = (j0 + j < n) ? kp_keys[base + j0 + j] : ~0ull;
-            __syncthreads();
-            const int m = min(1024, n - j0);
-            for (int j = 0; j < m; j++) rank += (tile[j] < key) ? 1 : 0;
-        }
-        if (i < n) kp_sorted[base + rank] = kp_tmp[base + i];
+    const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o], rbase = (size_t)frame * P.row_frame + P.row_off[o];
+    const unsigned int w = (unsigned int)P.w[o];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned long long key = kp_keys[base + i];
+        const unsigned int row = (unsigned int)(key >> 32) / w;
+        const int slot = row_start[rbase + row] + atomicAdd(&row_fill[rbase + row], 1);
+        bucket_keys[base + slot] = key;
+        bucket_src[base + slot] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void kp_row_rank_kernel(PyramidDesc P, const KeypointRec *__restrict__ kp_tmp,
+                                                         const unsigned long long *__restrict__ bucket_keys, const int32_t *__restrict__ bucket_src,
+                                                         const int32_t *__restrict__ kp_count, const int32_t *__restrict__ row_start,
+                                                         const int32_t *__restrict__ row_fill, KeypointRec *__restrict__ kp_sorted) {
+    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(kp_count[group], P.cap_kp[o]);
+    const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o], rbase = (size_t)frame * P.row_frame + P.row_off[o];
+    const unsigned int w = (unsigned int)P.w[o];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const unsigned long long key = bucket_keys[base + j];
+        const unsigned int row = (unsigned int)(key >> 32) / w;
+        const int b0 = row_start[rbase + row], b1 = b0 + row_fill[rbase + row];
+        int rank = b0;
+        for (int k = b0; k < b1; k++) rank += (bucket_keys[base + k] < key) ? 1 : 0;
+        kp_sorted[base + rank] = kp_tmp[base + bucket_src[base + j]];
     }
 }
 

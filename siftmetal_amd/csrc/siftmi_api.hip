@@ -73,7 +73,9 @@ struct siftmi_ctx {
     int input_slot = 0;
     ExtremumRec *d_ext = nullptr;
     KeypointRec *d_kp_tmp = nullptr, *d_kp = nullptr;
-    unsigned long long *d_keys = nullptr;
+    unsigned long long *d_keys = nullptr, *d_bucket_keys = nullptr;   // refine's sort keys; the same keys in row-bucket order
+    int32_t *d_bucket_src = nullptr, *d_row_count = nullptr, *d_row_start = nullptr;   // keypoint sort (kp_row_* kernels)
+    size_t row_table_ints = 0;
     int32_t *d_ori_count = nullptr;
     float *d_ori_angles = nullptr;
     DescInput *d_desc_in = nullptr;
@@ -189,7 +191,8 @@ extern "C" int siftmi_device_count(void) {
 static void free_ctx(siftmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_ori_count, c->d_ori_angles,
+    void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_bucket_keys, c->d_bucket_src, c->d_row_count,
+                    c->d_row_start, c->d_ori_count, c->d_ori_angles,
                     c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_state, c->d_out_kp,
                     c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out, c->d_match_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -284,6 +287,11 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     c->frame_stride = off;
     c->P.frame_stride = off; c->P.n_octaves = c->n_oct; c->P.nspo = nspo;
     c->P.ext_frame = ext_off; c->P.kp_frame = kp_off; c->P.desc_frame = desc_off;
+    {
+        size_t row_off = 0;
+        for (int o = 0; o < c->n_oct; o++) { c->P.row_off[o] = row_off; row_off += (size_t)(c->P.nspo + 2) * c->P.h[o]; }
+        c->P.row_frame = row_off;
+    }
     c->prm.dog_threshold = cfg->dog_threshold; c->prm.edge_threshold = cfg->edge_threshold;
     c->prm.max_offset = cfg->max_offset; c->prm.max_iterations = cfg->max_iterations;
     c->prm.border = cfg->image_border; c->prm.full_neighbourhood = cfg->full_neighbourhood;
@@ -306,6 +314,11 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     alloc((void **)&c->d_kp_tmp, B * kp_off * sizeof(KeypointRec));
     alloc((void **)&c->d_kp, B * kp_off * sizeof(KeypointRec));
     alloc((void **)&c->d_keys, B * kp_off * sizeof(unsigned long long));
+    alloc((void **)&c->d_bucket_keys, B * kp_off * sizeof(unsigned long long));
+    alloc((void **)&c->d_bucket_src, B * kp_off * sizeof(int32_t));
+    c->row_table_ints = B * c->P.row_frame;
+    alloc((void **)&c->d_row_count, c->row_table_ints * sizeof(int32_t));
+    alloc((void **)&c->d_row_start, c->row_table_ints * sizeof(int32_t));
     alloc((void **)&c->d_ori_count, B * kp_off * sizeof(int32_t));
     alloc((void **)&c->d_ori_angles, B * kp_off * ORI_BINS * sizeof(float));
     alloc((void **)&c->d_desc_in, B * desc_off * sizeof(DescInput));
@@ -494,12 +507,17 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
 static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
     const int groups = nf * c->n_oct;
     t_begin(c, SIFTMI_T_REFINE);
+    HIP_TRY(hipMemsetAsync(c->d_row_count, 0, (size_t)nf * c->P.row_frame * sizeof(int32_t), st));
     hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
-                       cnt(c, C_KP));
+                       cnt(c, C_KP), c->d_row_count);
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_SORT);
-    hipLaunchKernelGGL(sort_keypoints_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_keys, cnt(c, C_KP), c->d_kp);
+    hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, c->P, c->d_row_count, c->d_row_start);
+    hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
+                       c->d_bucket_keys, c->d_bucket_src);
+    hipLaunchKernelGGL(kp_row_rank_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_bucket_keys, c->d_bucket_src, cnt(c, C_KP),
+                       c->d_row_start, c->d_row_count, c->d_kp);
     HIP_TRY(hipGetLastError());
     t_end(c);
     return SIFTMI_OK;
