@@ -120,6 +120,10 @@ def main():
         if world > 1 or force_gather:
             runner.all_gather()
 
+    # reference counts from one synchronised step; every later step (graph replays included) must reproduce them
+    step()
+    barrier()
+    first = runner.results_host()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -136,6 +140,11 @@ def main():
     value = world * F * W * H * args.steps / dt / 1e6
 
     res = runner.results_host()
+    if (res["n_keypoints"], res["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]) or \
+            not np.array_equal(res["counts"], first["counts"]):
+        raise SystemExit("bench: results of the last timed step differ from the first step (%d/%d vs %d/%d keypoints/descriptors): "
+                         "the timed region did not compute the workload" %
+                         (res["n_keypoints"], res["n_descriptors"], first["n_keypoints"], first["n_descriptors"]))
     log("rank0 per-step: %d keypoints, %d descriptors over %d frames; %.3f ms/step, %.3f ms/frame" %
         (res["n_keypoints"], res["n_descriptors"], F, ms_per_step, ms_per_step / F))
 

@@ -189,6 +189,15 @@ int siftmi_match_descriptors(siftmi_ctx *ctx, const siftmi_descriptor *source, i
                              float absolute_threshold, float relative_threshold,
                              const siftmi_match **matches, int64_t *count);
 
+/* SIFTDescriptor.approximateMatch(source:target:absoluteThreshold:relativeThreshold:) (SIFT/SIFTDescriptor.swift:362-417)
+   over the reference's ANN trie (Utilities/Trie.swift:76-416): Trie(numberOfBins: 8) keyed by indexKey, radius 10, k 2.
+   Same results as the reference's pointer trie (the sorted path codes are its leaf ring).  Distances here are
+   IntVector.distance of the 0..255 features (not / 255): the reference's default absoluteThreshold is 300. */
+int siftmi_approximate_match(siftmi_ctx *ctx, const siftmi_descriptor *source, int64_t n_source,
+                             const siftmi_descriptor *target, int64_t n_target, int on_device,
+                             float absolute_threshold, float relative_threshold,
+                             const siftmi_match **matches, int64_t *count);
+
 /* SIFTDescriptor.matchGeometry(source:target:absoluteThreshold:relativeThreshold:) (SIFT/SIFTDescriptor.swift:104-144;
    compareGeometry :162-296): match on the GPU, then the geometric-consistency score of the first 80 matches
    (0 with fewer than 7 matches).  *_xy: the descriptors' keypoint absoluteCoordinate, [n][2] floats (x, y). */

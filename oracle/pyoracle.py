@@ -86,6 +86,20 @@ def lib():
         L.so_match_geometry.restype = C.c_float
         L.so_match_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                         C.POINTER(C.c_int)]
+        L.so_trie_create.restype = C.c_void_p
+        L.so_trie_create.argtypes = [C.c_int, C.c_void_p]
+        L.so_trie_destroy.argtypes = [C.c_void_p]
+        L.so_trie_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.so_trie_contains.restype = C.c_int
+        L.so_trie_contains.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.so_trie_capacity.restype = C.c_int
+        L.so_trie_capacity.argtypes = [C.c_void_p]
+        L.so_trie_link.restype = C.c_int
+        L.so_trie_link.argtypes = [C.c_void_p]
+        L.so_trie_nearest.restype = C.c_int
+        L.so_trie_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.so_approximate_match.restype = C.c_int
+        L.so_approximate_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -247,6 +261,50 @@ def match_geometry(src_features, src_xy, tgt_features, tgt_xy, absolute_threshol
     n = C.c_int(0)
     s = lib().so_match_geometry(_ptr(a), _ptr(axy), len(a), _ptr(b), _ptr(bxy), len(b), absolute_threshold, relative_threshold, C.byref(n))
     return float(s), n.value
+
+
+class Trie:
+    """Utilities/Trie.swift with descriptor ids as values (features: [n,128] ints the ids index)."""
+
+    def __init__(self, number_of_bins, features=None):
+        self.features = np.ascontiguousarray(features if features is not None else np.zeros((1, 128)), dtype=np.int32)
+        self.h = lib().so_trie_create(number_of_bins, _ptr(self.features))
+
+    def __del__(self):
+        try:
+            lib().so_trie_destroy(self.h)
+        except Exception:
+            pass
+
+    def insert(self, key, value):
+        k = np.ascontiguousarray(key, dtype=np.float32)
+        lib().so_trie_insert(self.h, _ptr(k), len(k), int(value))
+
+    def contains(self, key):
+        k = np.ascontiguousarray(key, dtype=np.float32)
+        return bool(lib().so_trie_contains(self.h, _ptr(k), len(k)))
+
+    def capacity(self):
+        return lib().so_trie_capacity(self.h)
+
+    def link(self):
+        return lib().so_trie_link(self.h)
+
+    def nearest(self, key, query, radius, k):
+        kk = np.ascontiguousarray(key, dtype=np.float32)
+        q = np.ascontiguousarray(query, dtype=np.int32)
+        ids, dist = np.zeros(8, np.int32), np.zeros(8, np.float32)
+        n = lib().so_trie_nearest(self.h, _ptr(kk), len(kk), _ptr(q), radius, k, _ptr(ids), _ptr(dist))
+        return list(zip(ids[:n].tolist(), dist[:n].tolist()))
+
+
+def approximate_match(src_features, tgt_features, absolute_threshold=300.0, relative_threshold=0.6):
+    """SIFTDescriptor.approximateMatch on [n,128] integer feature arrays -> structured array of correspondences."""
+    a = np.ascontiguousarray(src_features, dtype=np.int32)
+    b = np.ascontiguousarray(tgt_features, dtype=np.int32)
+    out = np.zeros(max(len(a), 1), match_dtype)
+    n = lib().so_approximate_match(_ptr(a), len(a), _ptr(b), len(b), absolute_threshold, relative_threshold, _ptr(out), len(out))
+    return out[:n].copy()
 
 
 def num_threads():

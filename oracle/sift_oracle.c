@@ -931,3 +931,197 @@ float so_match_geometry(const int32_t *src, const float *src_xy, int n_src, cons
     free(m);
     return score;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Sources/SIFTMetal/Utilities/Trie.swift:76-416  Trie (approximate nearest neighbour) and
+ * Sources/SIFTMetal/SIFT/SIFTDescriptor.swift:362-417  SIFTDescriptor.approximateMatch.
+ * A literal pointer trie: every node has numberOfBins children; a key component v in [0,1] selects child
+ * Int((v * Float(numberOfBins - 1)).rounded()) (:381-388); values live in the nodes reached by a whole key;
+ * link() chains the leaves (nodes without children) in depth-first child order into a ring (:118-127,141-158).
+ * Values are descriptor ids; their distance is IntVector.distance = sqrt(Float(sum of squared integer
+ * differences)) (Utilities/Vector.swift:45-59).                                                          */
+typedef struct so_trie_node {
+    struct so_trie_node **nodes;       /* [numberOfBins] */
+    int hasNodes;
+    int *values, n_values, cap_values;
+    struct so_trie_node *left, *right;
+} so_trie_node;
+
+struct so_trie {
+    int numberOfBins;
+    so_trie_node *root;
+    const int32_t *features;           /* [n][128], borrowed: value id -> descriptor */
+};
+
+static so_trie_node *so_trie_new_node(int nb) {
+    so_trie_node *n = (so_trie_node *)calloc(1, sizeof(so_trie_node));
+    n->nodes = (so_trie_node **)calloc((size_t)nb, sizeof(so_trie_node *));
+    return n;
+}
+
+static void so_trie_free_node(so_trie_node *n, int nb) {
+    if (!n) return;
+    for (int i = 0; i < nb; i++) so_trie_free_node(n->nodes[i], nb);
+    free(n->nodes); free(n->values); free(n);
+}
+
+so_trie *so_trie_create(int numberOfBins, const int32_t *features) {
+    so_trie *t = (so_trie *)calloc(1, sizeof(so_trie));
+    t->numberOfBins = numberOfBins; t->features = features;
+    t->root = so_trie_new_node(numberOfBins);
+    return t;
+}
+
+void so_trie_destroy(so_trie *t) {
+    if (!t) return;
+    so_trie_free_node(t->root, t->numberOfBins);
+    free(t);
+}
+
+static int so_trie_bin(const so_trie *t, float value) {                      /* binIndex(for:) :381-388 */
+    return (int)roundf(value * (float)(t->numberOfBins - 1));                /* .rounded(): half away from zero */
+}
+
+static int so_trie_wrap(const so_trie *t, int input) {                       /* wrapBinIndex :404-415 */
+    int output = input;
+    const int n = t->numberOfBins - 1;
+    if (output < 0) output += n;
+    else if (output >= n) output -= n;
+    return output;
+}
+
+void so_trie_insert(so_trie *t, const float *key, int len, int value) {      /* insert :160-194 */
+    so_trie_node *node = t->root;
+    for (int i = 0; i < len; i++) {
+        const int b = so_trie_bin(t, key[i]);
+        if (!node->nodes[b]) { node->nodes[b] = so_trie_new_node(t->numberOfBins); node->hasNodes = 1; }
+        node = node->nodes[b];
+    }
+    if (node->n_values == node->cap_values) {
+        node->cap_values = node->cap_values ? 2 * node->cap_values : 4;
+        node->values = (int *)realloc(node->values, sizeof(int) * (size_t)node->cap_values);
+    }
+    node->values[node->n_values++] = value;
+}
+
+int so_trie_contains(const so_trie *t, const float *key, int len) {          /* contains :196-214 */
+    const so_trie_node *node = t->root;
+    for (int i = 0; i < len; i++) {
+        const so_trie_node *next = node->nodes[so_trie_bin(t, key[i])];
+        if (!next) return 0;
+        node = next;
+    }
+    return 1;
+}
+
+static int so_trie_capacity_node(const so_trie_node *n, int nb) {            /* capacity :108-116 */
+    int total = n->n_values;
+    for (int i = 0; i < nb; i++) if (n->nodes[i]) total += so_trie_capacity_node(n->nodes[i], nb);
+    return total;
+}
+int so_trie_capacity(const so_trie *t) { return so_trie_capacity_node(t->root, t->numberOfBins); }
+
+static void so_trie_leaves(so_trie_node *n, int nb, so_trie_node ***list, int *count, int *cap) {   /* leaves :141-158 */
+    if (n->hasNodes) {
+        for (int i = 0; i < nb; i++) if (n->nodes[i]) so_trie_leaves(n->nodes[i], nb, list, count, cap);
+    } else {
+        if (*count == *cap) { *cap = *cap ? 2 * *cap : 64; *list = (so_trie_node **)realloc(*list, sizeof(so_trie_node *) * (size_t)*cap); }
+        (*list)[(*count)++] = n;
+    }
+}
+
+int so_trie_link(so_trie *t) {                                               /* link :118-127; returns the number of leaves */
+    so_trie_node **list = NULL;
+    int count = 0, cap = 0;
+    so_trie_leaves(t->root, t->numberOfBins, &list, &count, &cap);
+    for (int i = 0; i < count; i++) {
+        so_trie_node *thisNode = list[i], *nextNode = list[(i + 1) % count];
+        thisNode->right = nextNode;
+        nextNode->left = thisNode;
+    }
+    free(list);
+    return count;
+}
+
+static so_trie_node *so_trie_closest(const so_trie *t, so_trie_node *cur, int binIndex) {   /* closestNode :343-360 */
+    if (cur->nodes[binIndex]) return cur->nodes[binIndex];
+    int bestDistance = 0x7fffffff;
+    so_trie_node *bestNode = NULL;
+    for (int j = 0; j < t->numberOfBins; j++) {
+        if (!cur->nodes[j]) continue;
+        const int distance = so_trie_wrap(t, abs(j - binIndex));             /* binDifference :373-379 */
+        if (distance < bestDistance) { bestDistance = distance; bestNode = cur->nodes[j]; }
+    }
+    return bestNode;
+}
+
+static so_trie_node *so_trie_nearest_node(const so_trie *t, const float *key, int len) {    /* nearestNode :326-341 */
+    so_trie_node *current = t->root;
+    for (int i = 0; i < len; i++) {
+        if (!current->hasNodes) return current;
+        so_trie_node *node = so_trie_closest(t, current, so_trie_bin(t, key[i]));
+        if (!node) return current;
+        current = node;
+    }
+    return current;
+}
+
+/* FiniteQueue<Match> (:222-252): insert at the front, drop the last when over capacity */
+typedef struct { int value[8]; float distance[8]; int count, capacity; } so_trie_queue;
+
+static void so_trie_queue_insert(so_trie_queue *q, int value, float distance) {
+    const int n = q->count < 8 ? q->count : 7;
+    for (int i = n; i > 0; i--) { q->value[i] = q->value[i - 1]; q->distance[i] = q->distance[i - 1]; }
+    q->value[0] = value; q->distance[0] = distance;
+    q->count++;
+    if (q->count > q->capacity) q->count--;
+}
+
+static void so_trie_nearest_value(const so_trie *t, const so_trie_node *node, const int32_t *query, so_trie_queue *q) {   /* :362-377 */
+    float bestDistance = q->count ? q->distance[0] : 3.402823466e+38f;
+    for (int v = 0; v < node->n_values; v++) {
+        const int32_t *f = t->features + (size_t)node->values[v] * SO_DESC_FEATURES;
+        long k = 0;
+        for (int i = 0; i < SO_DESC_FEATURES; i++) { const long d = (long)f[i] - (long)query[i]; k += d * d; }
+        const float distance = sqrtf((float)k);
+        if (distance < bestDistance) { bestDistance = distance; so_trie_queue_insert(q, node->values[v], distance); }
+    }
+}
+
+/* nearest(key:query:radius:k:) :300-324 -> number of matches (<= k <= 8); ids / distances best first */
+int so_trie_nearest(const so_trie *t, const float *key, int len, const int32_t *query, int radius, int k, int *ids, float *distances) {
+    so_trie_queue q; memset(&q, 0, sizeof(q)); q.capacity = k < 8 ? k : 8;
+    so_trie_node *bin = so_trie_nearest_node(t, key, len);
+    so_trie_nearest_value(t, bin, query, &q);
+    so_trie_node *node = bin;
+    for (int r = 0; r < radius; r++) { node = node->left; so_trie_nearest_value(t, node, query, &q); }
+    node = bin;
+    for (int r = 0; r < radius; r++) { node = node->right; so_trie_nearest_value(t, node, query, &q); }
+    for (int i = 0; i < q.count; i++) { ids[i] = q.value[i]; distances[i] = q.distance[i]; }
+    return q.count;
+}
+
+/* SIFTDescriptor.approximateMatch(source:target:absoluteThreshold:relativeThreshold:) :362-417: Trie(numberOfBins: 8) keyed
+ * by indexKey, radius 10, k 2; a match needs two queue entries, best < absolute, best < second * relative. */
+int so_approximate_match(const int32_t *src, int n_src, const int32_t *tgt, int n_tgt, float absoluteThreshold, float relativeThreshold,
+                         so_match_rec *out, int cap) {
+    float *tkey = (float *)malloc(sizeof(float) * 16 * (size_t)(n_tgt > 0 ? n_tgt : 1));
+    float *skey = (float *)malloc(sizeof(float) * 16 * (size_t)(n_src > 0 ? n_src : 1));
+    so_descriptor_index(tgt, n_tgt, NULL, NULL, tkey);
+    so_descriptor_index(src, n_src, NULL, NULL, skey);
+    so_trie *t = so_trie_create(8, tgt);
+    for (int i = 0; i < n_tgt; i++) so_trie_insert(t, tkey + (size_t)i * 16, 16, i);
+    so_trie_link(t);
+    int count = 0;
+    for (int s = 0; s < n_src; s++) {
+        int ids[2]; float dist[2];
+        const int m = so_trie_nearest(t, skey + (size_t)s * 16, 16, src + (size_t)s * SO_DESC_FEATURES, 10, 2, ids, dist);
+        if (m != 2) continue;                                                /* :398-400 */
+        if (!(dist[0] < absoluteThreshold)) continue;
+        if (!(dist[0] < dist[1] * relativeThreshold)) continue;
+        if (out && count < cap) { out[count].source = s; out[count].target = ids[0]; out[count].distance = dist[0]; }
+        count++;
+    }
+    so_trie_destroy(t); free(tkey); free(skey);
+    return count;
+}

@@ -125,6 +125,19 @@ float so_compare_geometry(const so_match_rec *matches, int n, const float *src_x
 float so_match_geometry(const int32_t *src, const float *src_xy, int n_src, const int32_t *tgt, const float *tgt_xy, int n_tgt,
                         float absoluteThreshold, float relativeThreshold, int *n_matches);
 
+/* Trie (Utilities/Trie.swift:76-416) with descriptor ids as values, and SIFTDescriptor.approximateMatch
+   (SIFT/SIFTDescriptor.swift:362-417).  `features` ([n][128]) is borrowed and must outlive the trie. */
+typedef struct so_trie so_trie;
+so_trie *so_trie_create(int numberOfBins, const int32_t *features);
+void so_trie_destroy(so_trie *t);
+void so_trie_insert(so_trie *t, const float *key, int len, int value);
+int so_trie_contains(const so_trie *t, const float *key, int len);
+int so_trie_capacity(const so_trie *t);
+int so_trie_link(so_trie *t);
+int so_trie_nearest(const so_trie *t, const float *key, int len, const int32_t *query, int radius, int k, int *ids, float *distances);
+int so_approximate_match(const int32_t *src, int n_src, const int32_t *tgt, int n_tgt, float absoluteThreshold, float relativeThreshold,
+                         so_match_rec *out, int cap);
+
 int so_num_threads(void);
 
 #ifdef __cplusplus

@@ -219,6 +219,17 @@ class Engine:
             return np.zeros(0, _capi.match_dtype)
         return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 12,)).view(_capi.match_dtype).copy()
 
+    def approximate_match(self, source, target, absolute_threshold=300.0, relative_threshold=0.6):
+        """SIFTDescriptor.approximateMatch on descriptor records -> match records in source order."""
+        a = np.ascontiguousarray(source, dtype=descriptor_dtype)
+        b = np.ascontiguousarray(target, dtype=descriptor_dtype)
+        out, n = C.c_void_p(), C.c_int64()
+        _capi.check(self.L.siftmi_approximate_match(self.h, a.ctypes.data, len(a), b.ctypes.data, len(b), 0, absolute_threshold,
+                                                    relative_threshold, C.byref(out), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, _capi.match_dtype)
+        return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 12,)).view(_capi.match_dtype).copy()
+
     def match_geometry(self, source, source_xy, target, target_xy, absolute_threshold=1.176, relative_threshold=0.6):
         """SIFTDescriptor.matchGeometry on descriptor records + [n,2] (x, y) absolute coordinates -> (score, n_matches)."""
         a = np.ascontiguousarray(source, dtype=descriptor_dtype)
@@ -357,6 +368,12 @@ class SIFT:
         """SIFTDescriptor.match(source:target:absoluteThreshold:relativeThreshold:) (SIFTDescriptor.swift:298-318);
         a static function in the reference, hosted on the SIFT object here because it needs the device context."""
         m = self._engine.match(self._pack(source), self._pack(target), absoluteThreshold, relativeThreshold)
+        return [SIFTCorrespondence(source[int(r["source"])], target[int(r["target"])], float(r["distance"])) for r in m]
+
+    def approximateMatch(self, source: List[SIFTDescriptor], target: List[SIFTDescriptor], absoluteThreshold: float = 300,
+                         relativeThreshold: float = 0.6) -> List["SIFTCorrespondence"]:
+        """SIFTDescriptor.approximateMatch(source:target:absoluteThreshold:relativeThreshold:) (SIFTDescriptor.swift:362-388)."""
+        m = self._engine.approximate_match(self._pack(source), self._pack(target), absoluteThreshold, relativeThreshold)
         return [SIFTCorrespondence(source[int(r["source"])], target[int(r["target"])], float(r["distance"])) for r in m]
 
     def matchGeometry(self, source: List[SIFTDescriptor], target: List[SIFTDescriptor], absoluteThreshold: float = 1.176,

@@ -266,8 +266,8 @@ __device__ __forceinline__ bool out_of_bounds(int x, int y, int s, int w, int h,
 }
 
 // grid: (blocks, n_groups); group = frame * n_octaves + octave; grid-stride over the candidates.
-// Survivors are appended (unordered) to kp_tmp with a 64-bit sort key; sort_keypoints_kernel
-// orders them.
+// Survivors are appended (unordered) to kp_tmp with a 64-bit sort key; the kp_row_* kernels
+// order them.
 __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams prm,
                                                     const ExtremumRec *__restrict__ lists, const int32_t *__restrict__ cand_count,
                                                     KeypointRec *__restrict__ kp_tmp, unsigned long long *__restrict__ kp_keys,
@@ -354,6 +354,10 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
 // source index) into the buckets in arbitrary order; kp_row_rank_kernel ranks every entry inside its bucket (a row holds
 // a handful of keypoints) and moves the record.  O(n + rows) instead of the O(n^2) of a plain rank sort, which took
 // 3.9 ms of a 13 ms 8192 x 8192 tile (50 k keypoints in one group).
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
+}
+
 __global__ __launch_bounds__(1024) void kp_row_scan_kernel(PyramidDesc P, int32_t *__restrict__ row_count /* in: counts, out: zeros */,
                                                           int32_t *__restrict__ row_start) {
     __shared__ int wsum[16];

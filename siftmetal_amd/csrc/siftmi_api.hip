@@ -25,6 +25,8 @@
 #include "keypoint_kernels.hip.h"
 #include "match_kernels.hip.h"
 #include "host_post.h"
+#include "trie_kernels.hip.h"
+#include <rocprim/rocprim.hpp>
 
 using namespace siftmi;
 
@@ -471,7 +473,9 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     seed.format = format; seed.in_w = c->cfg.width; seed.in_h = c->cfg.height;
     SeedSource none; memset(&none, 0, sizeof(none));
     Decimate nodec; memset(&nodec, 0, sizeof(nodec));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 5 * (size_t)c->B * c->n_oct * sizeof(int32_t), st));
+    // Counters are cleared by a kernel, not hipMemsetAsync: memset nodes captured into the hipGraph stopped clearing from the
+    // third launch of a serial graph on (ROCm 7.2; tests/test_gpu_parity.py::test_graph_replays_stay_correct).
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters, 5 * (size_t)c->B * c->n_oct);
     t_begin(c, SIFTMI_T_SEED);
     HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed, nodec)));
     t_end(c);
@@ -507,7 +511,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
 static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
     const int groups = nf * c->n_oct;
     t_begin(c, SIFTMI_T_REFINE);
-    HIP_TRY(hipMemsetAsync(c->d_row_count, 0, (size_t)nf * c->P.row_frame * sizeof(int32_t), st));
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
     hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
                        cnt(c, C_KP), c->d_row_count);
     HIP_TRY(hipGetLastError());
@@ -584,7 +588,7 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
                          int32_t *d_counts, int32_t *d_totals, bool fork) {
     int rc;
     c->tstream = st;
-    HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t *)c->d_state, sizeof(PackState) / sizeof(int32_t));
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
@@ -748,7 +752,7 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     if ((rc = ensure_stats(c, n_frames))) return rc;
     hipStream_t st = c->stream;
     c->tstream = st;
-    HIP_TRY(hipMemsetAsync(c->d_state, 0, sizeof(PackState), st));
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t *)c->d_state, sizeof(PackState) / sizeof(int32_t));
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const void *d_px; size_t d_row, d_frame;
@@ -852,7 +856,7 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
         pos += counts[o];
     }
     HIP_TRY(hipMemcpyAsync(cnt(c, C_KP), h.data(), cs * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(cnt(c, C_ORIENTED), 0, 2 * cs * sizeof(int32_t), st));
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, cnt(c, C_ORIENTED), 2 * cs);
     int rc;
     if ((rc = run_describe(c, st, 1))) return rc;
     std::vector<int32_t> hc(5 * cs);
@@ -954,6 +958,61 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
     HIP_TRY(hipStreamSynchronize(st));
     for (const siftmi_match &m : all)
         if (m.target >= 0) c->h_matches.push_back(m);                        // source order (:304-314)
+    *count = (int64_t)c->h_matches.size();
+    if (matches) *matches = c->h_matches.data();
+    return SIFTMI_OK;
+}
+
+// SIFTDescriptor.approximateMatch (SIFT/SIFTDescriptor.swift:362-417) -- see trie_kernels.hip.h
+extern "C" int siftmi_approximate_match(siftmi_ctx *c, const siftmi_descriptor *source, int64_t n_source, const siftmi_descriptor *target,
+                                        int64_t n_target, int on_device, float absolute_threshold, float relative_threshold,
+                                        const siftmi_match **matches, int64_t *count) {
+    if (!c || !count || n_source < 0 || n_target < 0 || (n_source && !source) || (n_target && !target))
+        return set_error(SIFTMI_E_BADARG, "bad argument");
+    if (n_source > (1ll << 30) || n_target > (1ll << 30)) return set_error(SIFTMI_E_BADARG, "too many descriptors");
+    *count = 0;
+    c->h_matches.clear();
+    if (matches) *matches = c->h_matches.data();
+    if (n_source == 0 || n_target == 0) return SIFTMI_OK;                    // empty trie: no queue entries, every match is nil
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto grow = [&](void **p, long long *cap, long long need, size_t elem) -> int {
+        if (need <= *cap) return SIFTMI_OK;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; *cap = 0;
+        HIP_TRY(hipMalloc(p, (size_t)need * elem));
+        *cap = need;
+        return SIFTMI_OK;
+    };
+    int rc;
+    const DescriptorRec *d_src = (const DescriptorRec *)source, *d_tgt = (const DescriptorRec *)target;
+    if (!on_device) {
+        if ((rc = grow((void **)&c->d_match_src, &c->match_src_cap, n_source, sizeof(DescriptorRec)))) return rc;
+        if ((rc = grow((void **)&c->d_match_tgt, &c->match_tgt_cap, n_target, sizeof(DescriptorRec)))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_match_src, source, (size_t)n_source * sizeof(DescriptorRec), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_match_tgt, target, (size_t)n_target * sizeof(DescriptorRec), hipMemcpyHostToDevice, st));
+        d_src = c->d_match_src; d_tgt = c->d_match_tgt;
+    }
+    // scratch: codes in/out (u64), indices in/out (i32), then rocPRIM's temporary storage
+    size_t sort_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int32_t *)nullptr,
+                                      (int32_t *)nullptr, (size_t)n_target, 0, 48, st));
+    const long long words = n_target * 6 + (long long)((sort_bytes + 3) / 4) + 64;
+    if ((rc = grow((void **)&c->d_match_scratch, &c->match_scratch_cap, words, sizeof(int)))) return rc;
+    if ((rc = grow((void **)&c->d_match_out, &c->match_out_cap, n_source, sizeof(MatchRec)))) return rc;
+    unsigned long long *codes_in = (unsigned long long *)c->d_match_scratch, *codes = codes_in + n_target;
+    int32_t *idx_in = (int32_t *)(codes + n_target), *idx = idx_in + n_target;
+    void *sort_tmp = (void *)(idx + n_target + (n_target & 1));               // 8-byte aligned
+    hipLaunchKernelGGL(trie_code_kernel, dim3((unsigned)((n_target + 255) / 256)), dim3(256), 0, st, d_tgt, (int)n_target, codes_in, idx_in);
+    HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, codes_in, codes, idx_in, idx, (size_t)n_target, 0, 48, st));   // stable
+    hipLaunchKernelGGL(trie_query_kernel, dim3((unsigned)((n_source + 63) / 64)), dim3(64), 0, st, d_src, (int)n_source, d_tgt, codes, idx, (int)n_target,
+                       absolute_threshold, relative_threshold, c->d_match_out);
+    HIP_TRY(hipGetLastError());
+    std::vector<siftmi_match> all((size_t)n_source);
+    HIP_TRY(hipMemcpyAsync(all.data(), c->d_match_out, (size_t)n_source * sizeof(MatchRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (const siftmi_match &m : all)
+        if (m.target >= 0) c->h_matches.push_back(m);                        // source order (:375-386)
     *count = (int64_t)c->h_matches.size();
     if (matches) *matches = c->h_matches.data();
     return SIFTMI_OK;

@@ -1,5 +1,8 @@
-"""Batched frame stream on one GPU: frames and results stay in HBM (torch tensors own the memory,
-the HIP path runs on torch's current stream), optional RCCL all-gather of the packed results."""
+"""Batched frame stream on one GPU: frames and results stay in HBM (torch tensors own the memory), optional RCCL
+all-gather of the packed results.  The HIP path runs on a launch stream owned by the FrameStream, ordered after torch's
+current stream on entry and before it on exit, so torch work issued before run() (the frame upload) and after it
+(`.cpu()`, collectives) is ordered with the kernels whatever torch's current stream is -- including the default stream,
+whose handle is NULL and would otherwise select the context's own, unordered stream."""
 import numpy as np
 import torch
 
@@ -19,6 +22,7 @@ class FrameStream:
         self.counts = torch.zeros((2, frames_per_step, engine.n_octaves), dtype=torch.int32, device=device)
         self.totals = torch.zeros(2, dtype=torch.int32, device=device)
         self.gathered = None
+        self.launch_stream = torch.cuda.Stream(device=device)
 
     def run(self, d_frames):
         """d_frames: uint8 [F, H, W, 4] (BGRA) / [F, H, W] (gray) or float32 [F, H, W] device tensor."""
@@ -30,10 +34,13 @@ class FrameStream:
         else:
             fmt = _capi.FMT_GRAYF32
         es = d_frames.element_size()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        cur = torch.cuda.current_stream(self.device)
+        self.launch_stream.wait_stream(cur)
+        d_frames.record_stream(self.launch_stream)
         self.eng.detect_describe_batch_device(self.F, d_frames.data_ptr(), fmt, d_frames.stride(1) * es, d_frames.stride(0) * es,
                                               self.kp.data_ptr(), self.kp_cap, self.desc.data_ptr(), self.desc_cap,
-                                              self.counts.data_ptr(), self.totals.data_ptr(), stream)
+                                              self.counts.data_ptr(), self.totals.data_ptr(), self.launch_stream.cuda_stream)
+        cur.wait_stream(self.launch_stream)
 
     def all_gather(self):
         self.gathered = smdist.gather_results(self.kp, self.desc, self.counts, self.totals)

@@ -548,3 +548,79 @@ def test_reference_testMatches_flow_on_butterfly(sm, butterfly_bgra, ipol):
                                             ipol["desc_features"].astype(np.int32),
                                             np.array([d.keypoint.absoluteCoordinate for d in reference], np.float32), 300, 0.6)
     assert score == pytest.approx(want_score, rel=1e-6, nan_ok=True)
+
+
+@pytest.mark.parametrize("n_src,n_tgt", [(1, 1), (7, 3), (100, 15), (500, 3000), (3000, 20000)])
+def test_approximate_match_vs_oracle_trie(sm, n_src, n_tgt):
+    """SIFTDescriptor.approximateMatch: the sorted-code formulation on the GPU must give exactly what the oracle's pointer
+    trie gives (integer distances -> bit-identical floats)."""
+    from oracle import pyoracle
+    rng = np.random.default_rng(300 + n_src)
+    tgt = _sift_like(rng, n_tgt)
+    tgt[n_tgt // 2:] = tgt[:n_tgt - n_tgt // 2]                 # exact duplicates: several values per leaf, ties in distance
+    src = np.clip(tgt[rng.integers(0, n_tgt, n_src)] + rng.integers(-4, 5, (n_src, 128)), 0, 255).astype(np.int32)
+    src[::4] = _sift_like(rng, len(src[::4]))
+    eng = sm.Engine(64, 64, n_octaves=1)
+    for abs_thr, rel_thr in ((300.0, 0.6), (1e9, 2.0), (120.0, 0.9)):
+        got = eng.approximate_match(_records(sm, src), _records(sm, tgt), abs_thr, rel_thr)
+        want = pyoracle.approximate_match(src, tgt, abs_thr, rel_thr)
+        np.testing.assert_array_equal(got["source"], want["source"])
+        np.testing.assert_array_equal(got["target"], want["target"])
+        np.testing.assert_array_equal(got["distance"], want["distance"])
+    assert len(eng.approximate_match(_records(sm, src), _records(sm, tgt[:0]))) == 0
+    eng.close()
+
+
+def test_approximate_match_through_reference_api(sm):
+    from oracle import pyoracle
+    a = blob_frame(640, 480, 0, n_blobs=300)
+    b = np.roll(a, (2, 2), axis=(0, 1))
+    sift = sm.SIFT(device=0, configuration=sm.SIFT.Configuration(inputSize=sm.IntegralSize(640, 480)))
+    da = [d for o in sift.getDescriptors(sift.getKeypoints(a)) for d in o]
+    db = [d for o in sift.getDescriptors(sift.getKeypoints(b)) for d in o]
+    got = sift.approximateMatch(da, db)
+    want = pyoracle.approximate_match(np.array([d.features for d in da]), np.array([d.features for d in db]))
+    assert [(id(m.source), id(m.target)) for m in got] == [(id(da[int(w["source"])]), id(db[int(w["target"])])) for w in want]
+    assert len(got) > 20
+
+
+def test_frame_stream_is_ordered_with_torch_default_stream(sm):
+    """Regression: torch's default stream has a NULL handle, which the C ABI reads as "the context's own stream"; the
+    FrameStream must still order its kernels after the frame upload and before the result read-back, on the first call."""
+    import torch
+    from siftmetal_amd import stream as smstream
+    dev = torch.device("cuda", 0)
+    frame = blob_frame(640, 480, 3)
+    eng = sm.Engine(640, 480, n_octaves=3, max_batch=2)
+    _, kc, _, dc = eng.detect_describe_batch(np.stack([frame, frame]))
+    fs = smstream.FrameStream(eng, 2, device=dev)
+    assert torch.cuda.current_stream(dev).cuda_stream == 0
+    fs.run(torch.from_numpy(np.stack([frame, frame])).to(dev))          # temporary tensor, no explicit synchronisation
+    r = fs.results_host()
+    assert r["n_keypoints"] == int(kc.sum()) > 0 and r["n_descriptors"] == int(dc.sum()) > 0
+    np.testing.assert_array_equal(r["counts"][0], kc)
+    eng.close()
+
+
+@pytest.mark.parametrize("frames,lockstep", [(4, 4), (6, 4), (2, 2)])
+def test_graph_replays_stay_correct(sm, frames, lockstep):
+    """Regression: hipMemsetAsync nodes captured into the hipGraph stopped clearing the counters from the third launch on
+    (ROCm 7.2, non-forked graphs), so later replays accumulated garbage.  Counters are now cleared by a kernel; every
+    replay, synchronised and read back, must reproduce the host API's counts."""
+    import torch
+    from siftmetal_amd import stream as smstream
+    dev = torch.device("cuda", 0)
+    w, h = 1280, 960                                    # 4 frames x 2560 x 1920 > 16 Mpx: the serial (non-forked) graph
+    batch = np.stack([blob_frame(w, h, i) for i in range(frames)])
+    eng = sm.Engine(w, h, n_octaves=4, max_batch=lockstep)
+    _, kc, _, dc = eng.detect_describe_batch(batch)
+    fs = smstream.FrameStream(eng, frames, device=dev)
+    d = torch.from_numpy(batch).to(dev)
+    for launch in range(6):
+        fs.run(d)
+        torch.cuda.synchronize()
+        r = fs.results_host()
+        assert (r["n_keypoints"], r["n_descriptors"]) == (int(kc.sum()), int(dc.sum())), "launch %d" % launch
+        np.testing.assert_array_equal(r["counts"][0], kc)
+        np.testing.assert_array_equal(r["counts"][1], dc)
+    eng.close()
