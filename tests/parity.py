@@ -79,7 +79,7 @@ def compare_orientations(g_ori, r_ori, n_kp):
     """g_ori: siftmi_orientation records for all keypoints of the octave (count -1 = rejected);
     r_ori: oracle records (only the keypoints that passed the border filter)."""
     rc = {int(k): (int(c), th[:c]) for k, c, th in zip(r_ori["keypoint"], r_ori["count"], r_ori["orientations"])}
-    same_count, max_dt, n_cmp, mism = 0, 0.0, 0, 0
+    same_count, max_dt, n_cmp, mism, n_over = 0, 0.0, 0, 0, 0
     for k in range(n_kp):
         gc = int(g_ori["count"][k])
         if k not in rc:
@@ -92,9 +92,11 @@ def compare_orientations(g_ori, r_ori, n_kp):
             continue
         same_count += 1
         if c:
-            max_dt = max(max_dt, float(ang_diff(g_ori["orientations"][k][:c], th).max()))
+            d = ang_diff(g_ori["orientations"][k][:c], th)
+            max_dt = max(max_dt, float(d.max()))
+            n_over += int((d > TOL_THETA).sum())
             n_cmp += c
-    return {"n_kp": n_kp, "count_mismatch": mism, "max_dtheta": max_dt, "angles_compared": n_cmp}
+    return {"n_kp": n_kp, "count_mismatch": mism, "max_dtheta": max_dt, "angles_compared": n_cmp, "over_tol": n_over}
 
 
 def compare_descriptors(g_desc, g_f32, r_desc, r_f32, r_ori):
@@ -153,3 +155,90 @@ def to_oracle_orientations(g_ori):
     out["count"] = g_ori["count"][keep]
     out["orientations"] = g_ori["orientations"][keep]
     return out
+
+
+def _split(arr, counts):
+    out, pos = [], 0
+    for c in counts:
+        out.append(arr[pos:pos + c])
+        pos += c
+    return out
+
+
+def check_full_path(sm, img, no, nspo, strict_theta=True, **engine_kw):
+    """Every stage of the HIP path against the oracle on one image (used by tests/test_gpu_parity.py and
+    tools/fuzz_parity.py).  Raises AssertionError with the failing stage.
+
+    strict_theta=False (the randomised sweep): the reference's orientation histogram assigns each sample to the NEAREST bin
+    (round(36 theta / 2 pi), SIFTOrientation.metal:122-129), so it is discontinuous in the gradient angle: where a sample's
+    angle sits within an ulp of a bin boundary, two correct atan2f implementations put it into different bins, the histogram
+    changes by one whole sample (~1e-3 of a peak) and an interpolated peak on a flat histogram moves by up to ~1e-2 rad.
+    That happens to a fraction of a percent of the angles; the sweep therefore allows 2 % of the angles to exceed TOL_THETA,
+    none by more than 0.05 rad (under a third of a bin), instead of a hard maximum."""
+    import sys
+    from oracle import pyoracle
+    parity = sys.modules[__name__]
+    h, w = img.shape[:2]
+    eng = sm.Engine(w, h, n_octaves=no, nspo=nspo, keep_descriptor_floats=1, **engine_kw)
+    orc = pyoracle.Oracle(w, h, n_octaves=no, nspo=nspo)
+    NG = nspo + 3
+    ref = orc.run(img, want_float=True)
+
+    kps, kc, ds, dc = eng.detect_describe_batch(img[None])
+    st = eng.stats()
+    g_kp, g_ds = _split(kps, kc[0]), _split(ds, dc[0])
+
+    # schedule
+    for o in range(no):
+        assert eng.octave_size(o)[:2] == orc.octave_size(o) and eng.octave_size(o)[2] == orc.delta(o)
+        for s in range(NG):
+            assert eng.sigma(o, s) == orc.sigma(o, s)
+    for l in range(NG):
+        assert np.array_equal(eng.weights(l), orc.weights(l))
+
+    tot_kp = tot_match = 0
+    for o in range(no):
+        # 1. Gaussian stack: bit-exact
+        for s in range(NG):
+            G, R = eng.gaussian(o, s), orc.gaussian(o, s)
+            assert np.array_equal(G, R), "octave %d layer %d: max |d| = %g" % (o, s, np.abs(G - R).max())
+        # 2. extrema: identical raw count, identical candidate set
+        assert st["raw_extrema"][0, o] == len(ref[o]["extrema"])
+        cand = parity.prefilter_extrema(orc, o, ref[o]["extrema"])
+        assert parity.ext_set(eng.extrema(o)) == parity.ext_set(cand)
+        assert st["candidates"][0, o] == len(cand)
+        # 3. keypoints
+        rep, pairs = parity.compare_keypoints(g_kp[o], ref[o]["keypoints"])
+        tot_kp += max(rep["n_gpu"], rep["n_ref"]); tot_match += rep["matched"]
+        if pairs:
+            assert rep["max_abs_px"] <= parity.TOL_ABS_PX and rep["max_subscale"] <= parity.TOL_SUBSCALE
+            assert rep["max_value"] <= parity.TOL_VALUE and rep["max_sigma_rel"] <= parity.TOL_SIGMA_REL
+            assert rep["max_norm"] == 0.0
+        assert (g_kp[o]["octave"] == o).all()
+        # sorted by (scale, y, x)
+        key = g_kp[o]["scale"].astype(np.int64) * (1 << 40) + g_kp[o]["y"].astype(np.int64) * (1 << 20) + g_kp[o]["x"]
+        assert (np.diff(key) >= 0).all()
+        # 4./5. orientation + descriptors from IDENTICAL keypoints (the GPU's), so that float noise
+        # in refinement does not leak into the comparison of these stages
+        okp = parity.to_oracle_keypoints(g_kp[o])
+        r_ori = orc.orientations(o, okp)
+        g_ori = eng.orientations(o)
+        orep = parity.compare_orientations(g_ori, r_ori, len(okp))
+        assert orep["count_mismatch"] <= max(1, len(okp) // 200), orep
+        if strict_theta:
+            assert orep["max_dtheta"] <= parity.TOL_THETA, orep
+        else:
+            assert orep["over_tol"] <= max(1, orep["angles_compared"] // 50) and orep["max_dtheta"] <= 0.05, orep
+        assert st["oriented"][0, o] == int((g_ori["count"] >= 0).sum())
+        # ... and the descriptor stage from the GPU's own (keypoint, theta) list, bit-identical inputs
+        in_ori = parity.to_oracle_orientations(g_ori)
+        r_desc, r_f32 = orc.descriptors(o, okp, in_ori, want_float=True)
+        drep = parity.compare_descriptors(g_ds[o], eng.descriptor_floats(o), r_desc, r_f32, in_ori)
+        assert drep["max_dtheta"] == 0.0 and drep["n_gpu"] == drep["n_ref"], drep
+        assert drep["unmatched"] <= 2 * max(1, len(okp) // 200), drep
+        assert drep["max_bin_diff"] <= parity.MAX_DESC_BIN_DIFF, drep
+        assert drep["frac_differing"] <= parity.MAX_DESC_BIN_FRAC, drep
+        assert drep["max_l2_float"] <= parity.TOL_DESC_L2, drep
+    assert tot_match >= 0.995 * tot_kp - 1, (tot_match, tot_kp)
+    eng.close()
+    return {"keypoints": int(tot_kp), "matched": int(tot_match)}

@@ -50,65 +50,7 @@ def _image(name, size, butterfly_bgra):
 @pytest.mark.parametrize("name,size,no,nspo", CASES)
 def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no, nspo):
     img = _image(name, size, butterfly_bgra)
-    h, w = img.shape[:2]
-    eng = sm.Engine(w, h, n_octaves=no, nspo=nspo, keep_descriptor_floats=1)
-    orc = _oracle(w, h, no, nspo=nspo)
-    NG = nspo + 3
-    ref = orc.run(img, want_float=True)
-
-    kps, kc, ds, dc = eng.detect_describe_batch(img[None])
-    st = eng.stats()
-    g_kp, g_ds = _split(kps, kc[0]), _split(ds, dc[0])
-
-    # schedule
-    for o in range(no):
-        assert eng.octave_size(o)[:2] == orc.octave_size(o) and eng.octave_size(o)[2] == orc.delta(o)
-        for s in range(NG):
-            assert eng.sigma(o, s) == orc.sigma(o, s)
-    for l in range(NG):
-        assert np.array_equal(eng.weights(l), orc.weights(l))
-
-    tot_kp = tot_match = 0
-    for o in range(no):
-        # 1. Gaussian stack: bit-exact
-        for s in range(NG):
-            G, R = eng.gaussian(o, s), orc.gaussian(o, s)
-            assert np.array_equal(G, R), "octave %d layer %d: max |d| = %g" % (o, s, np.abs(G - R).max())
-        # 2. extrema: identical raw count, identical candidate set
-        assert st["raw_extrema"][0, o] == len(ref[o]["extrema"])
-        cand = parity.prefilter_extrema(orc, o, ref[o]["extrema"])
-        assert parity.ext_set(eng.extrema(o)) == parity.ext_set(cand)
-        assert st["candidates"][0, o] == len(cand)
-        # 3. keypoints
-        rep, pairs = parity.compare_keypoints(g_kp[o], ref[o]["keypoints"])
-        tot_kp += max(rep["n_gpu"], rep["n_ref"]); tot_match += rep["matched"]
-        if pairs:
-            assert rep["max_abs_px"] <= parity.TOL_ABS_PX and rep["max_subscale"] <= parity.TOL_SUBSCALE
-            assert rep["max_value"] <= parity.TOL_VALUE and rep["max_sigma_rel"] <= parity.TOL_SIGMA_REL
-            assert rep["max_norm"] == 0.0
-        assert (g_kp[o]["octave"] == o).all()
-        # sorted by (scale, y, x)
-        key = g_kp[o]["scale"].astype(np.int64) * (1 << 40) + g_kp[o]["y"].astype(np.int64) * (1 << 20) + g_kp[o]["x"]
-        assert (np.diff(key) >= 0).all()
-        # 4./5. orientation + descriptors from IDENTICAL keypoints (the GPU's), so that float noise
-        # in refinement does not leak into the comparison of these stages
-        okp = parity.to_oracle_keypoints(g_kp[o])
-        r_ori = orc.orientations(o, okp)
-        g_ori = eng.orientations(o)
-        orep = parity.compare_orientations(g_ori, r_ori, len(okp))
-        assert orep["count_mismatch"] <= max(1, len(okp) // 200), orep
-        assert orep["max_dtheta"] <= parity.TOL_THETA, orep
-        assert st["oriented"][0, o] == int((g_ori["count"] >= 0).sum())
-        # ... and the descriptor stage from the GPU's own (keypoint, theta) list, bit-identical inputs
-        in_ori = parity.to_oracle_orientations(g_ori)
-        r_desc, r_f32 = orc.descriptors(o, okp, in_ori, want_float=True)
-        drep = parity.compare_descriptors(g_ds[o], eng.descriptor_floats(o), r_desc, r_f32, in_ori)
-        assert drep["max_dtheta"] == 0.0 and drep["n_gpu"] == drep["n_ref"], drep
-        assert drep["unmatched"] <= 2 * max(1, len(okp) // 200), drep
-        assert drep["max_bin_diff"] <= parity.MAX_DESC_BIN_DIFF, drep
-        assert drep["frac_differing"] <= parity.MAX_DESC_BIN_FRAC, drep
-        assert drep["max_l2_float"] <= parity.TOL_DESC_L2, drep
-    assert tot_match >= 0.995 * tot_kp - 1, (tot_match, tot_kp)
+    parity.check_full_path(sm, img, no, nspo)
 
 
 def test_butterfly_against_ipol_fixtures(sm, butterfly_bgra, ipol):
