@@ -1,0 +1,88 @@
+"""Randomised API-sequence sweep: one long-lived context driven through random sequences of host batches, device-resident
+(hipGraph-replayed) batches, single-frame detect + describe and matcher calls, with every result compared bit for bit with
+per-frame results from a fresh lock-step-1 context.  Catches state leaking between calls (stale counters, graph replays,
+stream ordering).  Run on the GPU box:  python tools/fuzz_api.py [n_ops] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import siftmetal_amd as sm
+from siftmetal_amd import stream as smstream
+from tests.synth import blob_frame
+from oracle import pyoracle
+
+
+def main():
+    n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda", 0)
+    fails = 0
+    t0 = time.time()
+    for round_ in range(3):
+        w, h = [(640, 480), (1280, 960), (1920, 1080)][round_]
+        n_oct = int(rng.integers(2, 5))
+        B = int(rng.choice([1, 2, 3, 4, 8]))
+        pool = [blob_frame(w, h, 100 * round_ + i, n_blobs=int(rng.integers(20, 400))) for i in range(6)]
+        ref_eng = sm.Engine(w, h, n_octaves=n_oct, max_batch=1)
+        ref = []
+        for f in pool:
+            k, kc, d, dc = ref_eng.detect_describe_batch(f[None])
+            ref.append((k, kc[0], d, dc[0]))
+        ref_eng.close()
+        eng = sm.Engine(w, h, n_octaves=n_oct, max_batch=B)
+        streams = {}
+
+        def expect(ids):
+            return (np.concatenate([ref[i][0] for i in ids]), np.stack([ref[i][1] for i in ids]),
+                    np.concatenate([ref[i][2] for i in ids]), np.stack([ref[i][3] for i in ids]))
+
+        def check(tag, got, ids):
+            nonlocal fails
+            ek, ekc, ed, edc = expect(ids)
+            ok = (np.array_equal(got[1], ekc) and np.array_equal(got[3], edc) and got[0].tobytes() == ek.tobytes()
+                  and got[2].tobytes() == ed.tobytes())
+            print("%s %dx%d oct %d B %d: %s frames %s" % ("ok  " if ok else "FAIL", w, h, n_oct, B, tag, ids), flush=True)
+            fails += 0 if ok else 1
+
+        for op in range(n_ops // 3):
+            kind = rng.choice(["host", "device", "device", "single", "match"])
+            ids = [int(i) for i in rng.integers(0, len(pool), int(rng.integers(1, 2 * B + 2)))]
+            if kind == "host":
+                check("host batch", eng.detect_describe_batch(np.stack([pool[i] for i in ids])), ids)
+            elif kind == "device":
+                F = len(ids)
+                if F not in streams:
+                    streams[F] = smstream.FrameStream(eng, F, device=dev)
+                fs = streams[F]
+                reps = int(rng.integers(1, 5))
+                d = torch.from_numpy(np.stack([pool[i] for i in ids])).to(dev)
+                for _ in range(reps):
+                    fs.run(d)
+                    if rng.random() < 0.5:
+                        torch.cuda.synchronize()
+                r = fs.results_host()
+                check("device batch x%d" % reps, (r["keypoints"], r["counts"][0], r["descriptors"], r["counts"][1]), ids)
+            elif kind == "single":
+                i = ids[0]
+                kps, counts = eng.detect(pool[i])
+                ds, dc = eng.describe(kps, counts)
+                check("detect+describe", (kps, counts[None], ds, dc[None]), [i])
+            else:
+                i, j = ids[0], ids[-1]
+                m = eng.match(ref[i][2], ref[j][2])
+                want = pyoracle.match(ref[i][2]["features"].astype(np.int32), ref[j][2]["features"].astype(np.int32))
+                ok = np.array_equal(m["source"], want["source"]) and np.array_equal(m["target"], want["target"])
+                print("%s match %d vs %d: %d matches" % ("ok  " if ok else "FAIL", i, j, len(m)), flush=True)
+                fails += 0 if ok else 1
+        eng.close()
+    print("%d failures, %.0f s" % (fails, time.time() - t0), flush=True)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
