@@ -79,7 +79,13 @@ typedef struct siftmi_config {
     int32_t use_hip_graph;              /* 1 (default) = siftmi_detect_describe_batch_device captures its
                                            launch sequence into a hipGraph and replays it while the
                                            caller keeps passing the same buffers                    */
-    int32_t reserved[6];
+    int32_t count_raw_extrema;          /* 0 (default): on large launches the extrema scan skips image rows that the blur
+                                           kernels flagged as unable to hold a candidate (no |DoG| above 0.8 x
+                                           dog_threshold); same candidates, keypoints and descriptors, but the raw_extrema
+                                           statistic then counts tested rows only.  1 = scan every row, exact raw_extrema. */
+    int32_t blur_march_min_blocks;      /* launches with at least this many 128 x 128 workgroups use the marching blur
+                                           (default 2000; 1 = always, for tests) */
+    int32_t reserved[4];
 } siftmi_config;
 
 /* Replaces SIFTExtremaResult (Sources/MetalShaders/include/SIFTExtrema.h:14-18). */

@@ -30,7 +30,8 @@ class Config(C.Structure):
                 ("orientation_threshold", C.c_float), ("orientation_smoothing", C.c_int32),
                 ("descriptor_scales_per_octave", C.c_int32), ("full_neighbourhood", C.c_int32),
                 ("max_batch", C.c_int32), ("max_extrema", C.c_int32), ("max_keypoints", C.c_int32),
-                ("max_descriptors", C.c_int32), ("keep_descriptor_floats", C.c_int32), ("use_hip_graph", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("max_descriptors", C.c_int32), ("keep_descriptor_floats", C.c_int32), ("use_hip_graph", C.c_int32), ("count_raw_extrema", C.c_int32),
+                ("blur_march_min_blocks", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):

@@ -55,6 +55,17 @@ struct Decimate {
     int w2, h2;                     // next octave size
 };
 
+// Activity flags for the extrema scan (see extrema_kernel): while the blur that produces Gaussian layer s+1 still has
+// its output in registers it re-reads the input layer s (L2-hot: the workgroup fetched those rows one or two steps ago)
+// and records, per image row and 64-column cell, whether any |G[s+1] - G[s]| = |DoG[s]| exceeds the refinement-entry
+// threshold.  Exactly the subtraction and comparison the extrema kernel would do, so the flags are exact, not estimates.
+struct Activity {
+    unsigned char *dst;             // plane [h][ncell] of this DoG scale, frame 0 (nullptr = off)
+    size_t frame_stride;            // bytes between frames
+    int ncell;                      // cells per row = ceil(w / 64)
+    float thr;                      // 0.8 * dog_threshold (SIFTInterpolate.metal:208)
+};
+
 struct SeedSource {                 // input frame description for the seed loader
     const unsigned char *pixels;    // frame 0
     size_t frame_stride;            // bytes between frames
@@ -333,10 +344,10 @@ struct MarchGeom {
 
 template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */, int NTHR_ = 256,
           int ABL = 0 /* timing ablation: 1 = no FMAs, 2 = no LDS reads in the two passes (wrong results) */,
-          int TW_ = 128, int VSB = 4>
+          int TW_ = 128, int VSB = 4, bool ACT = false>
 __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
-                                                              int n_frames, int spc /* steps per chunk */, Decimate dec) {
+                                                              int n_frames, int spc /* steps per chunk */, Decimate dec, Activity act) {
     using G = MarchGeom<R, S_, NTHR_, TW_>;
     constexpr int QW = G::TW / 4, QSH = (QW == 64 ? 6 : 5);     // float4 columns per row
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -439,6 +450,17 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
         {
             const int cg = tid & (QW - 1), rg = tid >> QSH;
             const float *colp = lds + (rg * G::RB) * G::LW + G::RP + cg * 4;
+            // activity flags: the input-layer values under this lane's outputs, requested before the FMA phase so that
+            // they land under it (same rows this workgroup fetched a step or two ago: L2 hits)
+            float4 rawv[ACT ? G::RB : 1];
+            const bool raw_fast = ACT && (w & 3) == 0 && x0 + cg * 4 + 3 < w;
+            if (ACT && raw_fast) {
+#pragma unroll
+                for (int rr = 0; rr < G::RB; rr++) {
+                    const int gy = min(y0 + rg * G::RB + rr, h - 1);
+                    rawv[rr] = *reinterpret_cast<const float4 *>(in + (size_t)gy * w + x0 + cg * 4);
+                }
+            }
             float4 acc[G::RB];
 #pragma unroll
             for (int rr = 0; rr < G::RB; rr++) acc[rr] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -481,6 +503,23 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
                     float *o2 = dec.dst + (size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1);
                     if ((gx >> 1) + 0 < dec.w2 && gx + 0 < w) o2[0] = acc[rr].x;
                     if ((gx >> 1) + 1 < dec.w2 && gx + 2 < w) o2[1] = acc[rr].z;
+                }
+                if (ACT) {                                  // 16 lanes = 64 columns = one cell of this row
+                    static_assert(!ACT || G::TW == 128, "activity cells assume 128-column strips");
+                    const float *ip = in + (size_t)gy * w + gx;
+                    bool f;
+                    if (raw_fast) {
+                        const float4 raw = rawv[rr];
+                        f = fabsf(acc[rr].x - raw.x) > act.thr || fabsf(acc[rr].y - raw.y) > act.thr || fabsf(acc[rr].z - raw.z) > act.thr ||
+                            fabsf(acc[rr].w - raw.w) > act.thr;
+                    } else {
+                        f = (gx + 0 < w && fabsf(acc[rr].x - ip[0]) > act.thr) || (gx + 1 < w && fabsf(acc[rr].y - ip[1]) > act.thr) ||
+                            (gx + 2 < w && fabsf(acc[rr].z - ip[2]) > act.thr) || (gx + 3 < w && fabsf(acc[rr].w - ip[3]) > act.thr);
+                    }
+                    const unsigned long long b = __ballot(f);
+                    const int lane = tid & 63, cell = (x0 >> 6) + ((lane >> 4) & 1);
+                    if ((lane & 15) == 0 && cell < act.ncell)
+                        act.dst[(size_t)frame * act.frame_stride + (size_t)gy * act.ncell + cell] = ((b >> (lane & 48)) & 0xffffull) ? 1 : 0;
                 }
             }
         }

@@ -77,10 +77,17 @@ __device__ __forceinline__ const float *layer_ptr(const PyramidDesc &p, int fram
 // every strict extremum.
 constexpr int EXT_COLS_PER_WAVE = 62, EXT_COLS_PER_BLOCK = 4 * EXT_COLS_PER_WAVE;
 
-template <int NS>
+// SKIP: the blur kernels left per-(DoG scale, row, 64-column cell) activity flags (dense_kernels.hip.h, struct Activity):
+// "some |DoG| here exceeds the refinement-entry threshold".  A candidate needs that at its own pixel, so a row without
+// an active cell under this wave cannot emit one; such rows are not tested, and a row is not even loaded unless it or a
+// vertical neighbour is active.  On the benchmark frames 88 % of octave 0's row segments are inactive.  The emitted
+// candidate list is exactly the same; raw_count then only counts the extrema of tested rows (cfg.count_raw_extrema = 1
+// turns the flags off and restores the full count).
+template <int NS, bool SKIP = false>
 __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParams prm, int o, int EH,
                                                      ExtremumRec *__restrict__ lists, int32_t *__restrict__ cand_count,
-                                                     int32_t *__restrict__ raw_count) {
+                                                     int32_t *__restrict__ raw_count, const unsigned char *__restrict__ act /* octave planes, frame 0 */,
+                                                     size_t act_frame_stride, int ncell) {
     constexpr int ND = NS + 2;
     // Workgroup-level staging (as the reference's threadgroup array, SIFTExtrema.metal:71-75, 101-109):
     // one global atomic per workgroup and counter.  A single device-scope counter serialises at
@@ -168,14 +175,55 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
             }
         }
     };
-    issue(ya - 1); finish(ra);
-    issue(ya); finish(rb);
-    issue(ya + 1);
-    for (int y = ya; y < yb; y += 3) {
-        finish(rc); issue(y + 2);
-        test_row(y, ra, rb, rc);
-        if (y + 1 < yb) { finish(ra); issue(y + 3); test_row(y + 1, rb, rc, ra); }
-        if (y + 2 < yb) { finish(rb); issue(y + 4); test_row(y + 2, rc, ra, rb); }
+    if (!SKIP) {
+        issue(ya - 1); finish(ra);
+        issue(ya); finish(rb);
+        issue(ya + 1);
+        for (int y = ya; y < yb; y += 3) {
+            finish(rc); issue(y + 2);
+            test_row(y, ra, rb, rc);
+            if (y + 1 < yb) { finish(ra); issue(y + 3); test_row(y + 1, rb, rc, ra); }
+            if (y + 2 < yb) { finish(rb); issue(y + 4); test_row(y + 2, rc, ra, rb); }
+        }
+    } else {
+        // bit i of `centre`: row ya - 1 + i is an output row of this block with an active cell under this wave's columns;
+        // bit i of `need`: that row, or the one above or below it, is such a row, so its values are read.  Wave-uniform.
+        const int xw = blockIdx.x * EXT_COLS_PER_BLOCK + wv * EXT_COLS_PER_WAVE;          // column of lane 0
+        const int c0 = min((xw + 1) >> 6, ncell - 1), c1 = min((xw + EXT_COLS_PER_WAVE) >> 6, ncell - 1);
+        const unsigned char *ap = act + (size_t)frame * act_frame_stride;
+        bool a = false;
+        const int row = ya - 1 + lane;
+        if (lane >= 1 && row < yb) {
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const unsigned char *q = ap + ((size_t)s * h + row) * ncell;
+                a = a || q[c0] || q[c1];
+            }
+        }
+        const unsigned long long centre = __ballot(a);
+        const unsigned long long need = centre | (centre << 1) | (centre >> 1);
+        auto needs = [&](int y) { return ((need >> (y - (ya - 1))) & 1ull) != 0; };        // rows ya-1 ... yb
+        auto tests = [&](int y) { return ((centre >> (y - (ya - 1))) & 1ull) != 0; };
+        if (need != 0ull) {
+            if (needs(ya - 1)) { issue(ya - 1); finish(ra); }
+            if (needs(ya)) { issue(ya); finish(rb); }
+            if (needs(ya + 1)) issue(ya + 1);
+            for (int y = ya; y < yb; y += 3) {
+                if (needs(y + 1)) finish(rc);
+                if (y + 2 <= yb && needs(y + 2)) issue(y + 2);
+                if (tests(y)) test_row(y, ra, rb, rc);
+                if (y + 1 < yb) {
+                    if (needs(y + 2)) finish(ra);
+                    if (y + 3 <= yb && needs(y + 3)) issue(y + 3);
+                    if (tests(y + 1)) test_row(y + 1, rb, rc, ra);
+                }
+                if (y + 2 < yb) {
+                    if (needs(y + 3)) finish(rb);
+                    if (y + 4 <= yb && needs(y + 4)) issue(y + 4);
+                    if (tests(y + 2)) test_row(y + 2, rc, ra, rb);
+                }
+            }
+        }
     }
     __syncthreads();
     const int nloc = min(s_cand, STAGE);

@@ -77,6 +77,11 @@ struct siftmi_ctx {
     KeypointRec *d_kp_tmp = nullptr, *d_kp = nullptr;
     unsigned long long *d_keys = nullptr, *d_bucket_keys = nullptr;   // refine's sort keys; the same keys in row-bucket order
     int32_t *d_bucket_src = nullptr, *d_row_count = nullptr, *d_row_start = nullptr;   // keypoint sort (kp_row_* kernels)
+    unsigned char *d_act = nullptr;           // DoG activity flags [B][octave][nspo][h][ncell] written by the marching blur
+    long long march_min_blocks = 2000;
+    size_t act_off[MAX_OCT] = {0}, act_frame = 0;
+    int act_ncell[MAX_OCT] = {0};
+    bool act_valid[MAX_OCT] = {false};        // this sub-batch's flags of the octave are complete (all its layers used the marching blur)
     size_t row_table_ints = 0;
     int32_t *d_ori_count = nullptr;
     float *d_ori_angles = nullptr;
@@ -179,6 +184,8 @@ extern "C" int siftmi_default_config(siftmi_config *cfg, int32_t width, int32_t 
     cfg->full_neighbourhood = 0;
     cfg->max_batch = 1;
     cfg->use_hip_graph = 1;
+    cfg->count_raw_extrema = 0;
+    cfg->blur_march_min_blocks = 2000;
     return SIFTMI_OK;
 }
 
@@ -194,7 +201,7 @@ static void free_ctx(siftmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_bucket_keys, c->d_bucket_src, c->d_row_count,
-                    c->d_row_start, c->d_ori_count, c->d_ori_angles,
+                    c->d_row_start, c->d_act, c->d_ori_count, c->d_ori_angles,
                     c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_state, c->d_out_kp,
                     c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out, c->d_match_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -237,6 +244,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     c->cfg = *cfg;
     c->device = hip_device;
     c->n_oct = cfg->n_octaves; c->nspo = cfg->nspo; c->B = cfg->max_batch;
+    c->march_min_blocks = cfg->blur_march_min_blocks > 0 ? cfg->blur_march_min_blocks : 2000;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_launches, 0, sizeof(c->t_launches));
     const int W = cfg->width, H = cfg->height, nspo = cfg->nspo, NG = nspo + 3;
 
@@ -318,6 +326,16 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     alloc((void **)&c->d_keys, B * kp_off * sizeof(unsigned long long));
     alloc((void **)&c->d_bucket_keys, B * kp_off * sizeof(unsigned long long));
     alloc((void **)&c->d_bucket_src, B * kp_off * sizeof(int32_t));
+    {
+        size_t off_b = 0;
+        for (int o = 0; o < c->n_oct; o++) {
+            c->act_ncell[o] = (c->ow[o] + 63) / 64;
+            c->act_off[o] = off_b;
+            off_b += (size_t)c->nspo * c->oh[o] * c->act_ncell[o];
+        }
+        c->act_frame = (off_b + 15) & ~(size_t)15;
+    }
+    alloc((void **)&c->d_act, B * c->act_frame);
     c->row_table_ints = B * c->P.row_frame;
     alloc((void **)&c->d_row_count, c->row_table_ints * sizeof(int32_t));
     alloc((void **)&c->d_row_start, c->row_table_ints * sizeof(int32_t));
@@ -369,9 +387,17 @@ static void t_collect(siftmi_ctx *c) {
 
 // ------------------------------------------------------------------------------------------------
 // launches
+// the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 2000)
+static bool uses_march(const siftmi_ctx *c, int w, int h, int nf) {
+    using Gm = MarchGeom<1, 16>;
+    const int spc = 8;
+    const long long total = (long long)((w + Gm::TW - 1) / Gm::TW) * ((h + spc * Gm::S - 1) / (spc * Gm::S)) * nf;
+    return total >= c->march_min_blocks;
+}
+
 template <int R, bool SEED, bool DEC>
 static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
-                                 const TapWeights &wt, const SeedSource &seed, const Decimate &dec) {
+                                 const TapWeights &wt, const SeedSource &seed, const Decimate &dec, const Activity &act) {
     bool march = false;
     if constexpr (!SEED) {
         // large launches: marching form (no vertical-halo recompute, next rows prefetched under the FMA phases);
@@ -381,11 +407,15 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
         using Gm = MarchGeom<R, S>;
         const int spc = 8;
         const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + spc * Gm::S - 1) / (spc * Gm::S)) * nf;
-        if (total >= 2000) {
+        if (uses_march(c, w, h, nf)) {
             march = true;
             dim3 grid(((total + 7) / 8) * 8, 1, 1);
-            hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
-                               c->frame_stride, wt, nf, spc, dec);
+            if (act.dst)
+                hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC, false, 256, 0, 128, 4, true>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h,
+                                   c->frame_stride, c->frame_stride, wt, nf, spc, dec, act);
+            else
+                hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
+                                   c->frame_stride, wt, nf, spc, dec, act);
         }
     }
     if (!march) {
@@ -401,18 +431,18 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
 
 template <int R, bool SEED>
 static hipError_t launch_blur_r(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
-                                const TapWeights &wt, const SeedSource &seed, const Decimate &dec) {
+                                const TapWeights &wt, const SeedSource &seed, const Decimate &dec, const Activity &act) {
     if constexpr (!SEED) {
-        if (dec.dst) return launch_blur_rd<R, SEED, true>(c, st, src, dst, w, h, nf, wt, seed, dec);
+        if (dec.dst) return launch_blur_rd<R, SEED, true>(c, st, src, dst, w, h, nf, wt, seed, dec, act);
     }
-    return launch_blur_rd<R, SEED, false>(c, st, src, dst, w, h, nf, wt, seed, dec);
+    return launch_blur_rd<R, SEED, false>(c, st, src, dst, w, h, nf, wt, seed, dec, act);
 }
 
 template <bool SEED>
 static hipError_t launch_blur(siftmi_ctx *c, hipStream_t st, int radius, const float *src, float *dst, int w, int h, int nf,
-                              const TapWeights &wt, const SeedSource &seed, const Decimate &dec) {
+                              const TapWeights &wt, const SeedSource &seed, const Decimate &dec, const Activity &act = Activity{nullptr, 0, 0, 0.0f}) {
     switch (radius) {
-#define CASE_R(r) case r: return launch_blur_r<r, SEED>(c, st, src, dst, w, h, nf, wt, seed, dec);
+#define CASE_R(r) case r: return launch_blur_r<r, SEED>(c, st, src, dst, w, h, nf, wt, seed, dec, act);
         CASE_R(1) CASE_R(2) CASE_R(3) CASE_R(4) CASE_R(5) CASE_R(6) CASE_R(7) CASE_R(8)
         CASE_R(9) CASE_R(10) CASE_R(11) CASE_R(12) CASE_R(13) CASE_R(14) CASE_R(15)
 #undef CASE_R
@@ -439,11 +469,22 @@ static int ensure_fork(siftmi_ctx *c) {
 }
 
 static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
-    const int EH = 33;                                  // multiple of 3: the row loop is unrolled 3x
     if (c->ow[o] < 3 || c->oh[o] < 3) return SIFTMI_OK;
+    // rows per workgroup, a multiple of 3 (the row loop is unrolled 3x); with activity flags one lane per window row
+    // fetches the flags, so EH + 2 <= 64, and taller blocks amortise that fetch
+    const int EH = c->act_valid[o] ? 60 : 33;
     t_begin(c, SIFTMI_T_EXTREMA);
     dim3 grid((c->ow[o] - 2 + EXT_COLS_PER_BLOCK - 1) / EXT_COLS_PER_BLOCK, (c->oh[o] - 2 + EH - 1) / EH, nf);
-#define LAUNCH_EXT(NS) hipLaunchKernelGGL((extrema_kernel<NS>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW))
+    const unsigned char *actp = c->act_valid[o] ? c->d_act + c->act_off[o] : nullptr;
+#define LAUNCH_EXT(NS)                                                                                                                    \
+    do {                                                                                                                                  \
+        if (actp)                                                                                                                         \
+            hipLaunchKernelGGL((extrema_kernel<NS, true>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW), actp, \
+                               c->act_frame, c->act_ncell[o]);                                                                            \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((extrema_kernel<NS, false>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW), actp, \
+                               c->act_frame, c->act_ncell[o]);                                                                            \
+    } while (0)
     switch (c->nspo) {
         case 1: LAUNCH_EXT(1); break;
         case 2: LAUNCH_EXT(2); break;
@@ -483,14 +524,21 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     bool joined[MAX_OCT] = {};
     for (int o = 0; o < c->n_oct; o++) {
         hipStream_t next = cur;
+        // DoG activity flags for the extrema scan: only when every layer of this octave goes through the marching blur
+        c->act_valid[o] = !c->cfg.count_raw_extrema && c->ow[o] >= 3 && c->oh[o] >= 3 && uses_march(c, c->ow[o], c->oh[o], nf);
         for (int s = 1; s < NG; s++) {
             Decimate dec = nodec;
             if (s == c->nspo && o + 1 < c->n_oct) {
                 dec.dst = gauss_ptr(c, o + 1, 0); dec.frame_stride = c->frame_stride; dec.w2 = c->ow[o + 1]; dec.h2 = c->oh[o + 1];
             }
+            // layers 2 ... nspo+1 complete DoG scales 1 ... nspo, the ones that can hold a candidate
+            Activity act{nullptr, 0, 0, 0.0f};
+            if (c->act_valid[o] && s >= 2 && s <= c->nspo + 1)
+                act = Activity{c->d_act + c->act_off[o] + (size_t)(s - 2) * c->oh[o] * c->act_ncell[o], c->act_frame, c->act_ncell[o],
+                               c->prm.dog_threshold * 0.8f};
             t_begin(c, SIFTMI_T_BLUR);
             HIP_TRY((launch_blur<false>(c, cur, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
-                                        nf, c->layer_w[s - 1], none, dec)));
+                                        nf, c->layer_w[s - 1], none, dec, act)));
             t_end(c);
             if (fork && s == c->nspo && o + 1 < c->n_oct) {          // next octave can start now, on its own stream
                 HIP_TRY(hipEventRecord(c->ev_fork[o], cur));

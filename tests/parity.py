@@ -203,7 +203,12 @@ def check_full_path(sm, img, no, nspo, strict_theta=True, **engine_kw):
             G, R = eng.gaussian(o, s), orc.gaussian(o, s)
             assert np.array_equal(G, R), "octave %d layer %d: max |d| = %g" % (o, s, np.abs(G - R).max())
         # 2. extrema: identical raw count, identical candidate set
-        assert st["raw_extrema"][0, o] == len(ref[o]["extrema"])
+        # raw count: exact unless the extrema scan skips rows flagged inactive by the marching blur (cfg.count_raw_extrema = 0
+        # on launches that use it; small images only do when blur_march_min_blocks forces it)
+        if engine_kw.get("count_raw_extrema", 0) or "blur_march_min_blocks" not in engine_kw:
+            assert st["raw_extrema"][0, o] == len(ref[o]["extrema"])
+        else:
+            assert st["raw_extrema"][0, o] <= len(ref[o]["extrema"])
         cand = parity.prefilter_extrema(orc, o, ref[o]["extrema"])
         assert parity.ext_set(eng.extrema(o)) == parity.ext_set(cand)
         assert st["candidates"][0, o] == len(cand)
