@@ -33,7 +33,7 @@ def collect(d, name):
             if r["Counter_Name"] != name: continue
             k = r["Kernel_Name"]
             if "blur_march_kernel" not in k: continue        # the octave-0 launches of tools/prof_blur.py use the marching kernel
-            vals[(k.split("(")[0][-60:], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+            vals[(k.split("(")[0][-90:], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return vals
 fetch, write = collect("fetch", "FETCH_SIZE"), collect("write", "WRITE_SIZE")
 res = []
