@@ -131,8 +131,12 @@ struct siftmi_ctx {
             return px == o.px && n_frames == o.n_frames && format == o.format && row_stride == o.row_stride && frame_stride == o.frame_stride &&
                    kp == o.kp && kp_cap == o.kp_cap && desc == o.desc && desc_cap == o.desc_cap && counts == o.counts && totals == o.totals && st == o.st;
         }
-    } gkey{};
-    hipGraphExec_t gexec = nullptr;
+    };
+    // Captured launch sequences, most recently used last; up to GCACHE_MAX call signatures per context, further ones run
+    // with direct launches.  Executable graphs are never destroyed (runtime defect, see drop_graphs()).
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
+    std::vector<GraphEntry> gcache;
+    static constexpr size_t GCACHE_MAX = 64;
     bool graph_failed = false;
     // fork/join of the octave chains inside a captured graph (small launches only, see run_dense_detect)
     hipStream_t oct_stream[MAX_OCT] = {};
@@ -200,6 +204,7 @@ extern "C" int siftmi_device_count(void) {
 static void free_ctx(siftmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();             // nothing of this context may still be running when its memory and graphs go
     void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_bucket_keys, c->d_bucket_src, c->d_row_count,
                     c->d_row_start, c->d_act, c->d_ori_count, c->d_ori_angles,
                     c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_state, c->d_out_kp,
@@ -207,7 +212,7 @@ static void free_ctx(siftmi_ctx *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    c->gcache.clear();                        // executable graphs are abandoned, not destroyed: see drop_graphs()
     for (int i = 0; i < MAX_OCT; i++) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -609,8 +614,22 @@ static int run_pack(siftmi_ctx *c, hipStream_t st, int nf, int frame_base, int t
     return SIFTMI_OK;
 }
 
+// captured graphs hold raw pointers into the context's buffers: drop them (device idle) before any such buffer is replaced
+// Executable graphs are never destroyed.  With the HIP runtime of this image (ROCm 7.0 build bundled with PyTorch 2.10)
+// hipGraphExecDestroy leaves the runtime in a state in which a later hipGraphLaunch of ANOTHER executable graph
+// dereferences a null pointer -- about 1 in 10 runs of tools/fuzz_api.py (600 random operations) segfaulted inside
+// hipGraphLaunch, none in 80 runs without the destroy calls.  A context therefore keeps at most GCACHE_MAX captured
+// signatures, runs further ones with direct launches, and abandons (leaks, a few hundred kB each) the graphs it can no
+// longer use: when a buffer they point into is replaced, and when the context is destroyed.
+static void drop_graphs(siftmi_ctx *c) {
+    if (c->gcache.empty()) return;
+    (void)hipDeviceSynchronize();
+    c->gcache.clear();
+}
+
 static int ensure_stats(siftmi_ctx *c, int n_frames) {
     if (n_frames <= c->out_frames_cap) return SIFTMI_OK;
+    drop_graphs(c);                                       // they write the per-frame statistics block that is replaced below
     if (c->d_out_counts) (void)hipFree(c->d_out_counts);
     if (c->d_stats) (void)hipFree(c->d_stats);
     c->d_out_counts = nullptr; c->d_stats = nullptr; c->out_frames_cap = 0;
@@ -666,8 +685,16 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
     if (want_graph) {
         const siftmi_ctx::GraphKey key{d_pixels, n_frames, format, row_stride, frame_stride, d_keypoints, (long long)kp_capacity, d_descriptors,
                                        (long long)desc_capacity, d_counts, d_totals, st};
-        if (!(c->gexec && key == c->gkey)) {
-            if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        hipGraphExec_t exec = nullptr;
+        for (size_t i = 0; i < c->gcache.size(); i++)
+            if (c->gcache[i].key == key) {                       // hit: move to the back (most recently used)
+                const siftmi_ctx::GraphEntry hit = c->gcache[i];
+                c->gcache.erase(c->gcache.begin() + (long)i);
+                c->gcache.push_back(hit);
+                exec = hit.exec;
+                break;
+            }
+        if (!exec && c->gcache.size() < siftmi_ctx::GCACHE_MAX) {
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
@@ -676,20 +703,20 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
                 rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
                                    (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals, fork);
                 e = hipStreamEndCapture(st, &graph);
-                if (rc == SIFTMI_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+                if (rc == SIFTMI_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 else if (rc == SIFTMI_OK && e == hipSuccess) e = hipErrorUnknown;
                 if (graph) (void)hipGraphDestroy(graph);
             }
-            if (rc != SIFTMI_OK || e != hipSuccess || !c->gexec) {
+            if (rc != SIFTMI_OK || e != hipSuccess || !exec) {
                 (void)hipGetLastError();
-                c->gexec = nullptr;
+                exec = nullptr;
                 c->graph_failed = true;          // fall through to direct launches, now and later
             } else {
-                c->gkey = key;
+                c->gcache.push_back(siftmi_ctx::GraphEntry{key, exec});
             }
         }
-        if (c->gexec) {
-            HIP_TRY(hipGraphLaunch(c->gexec, st));
+        if (exec) {
+            HIP_TRY(hipGraphLaunch(exec, st));
             c->last_sub_frames = std::min(c->B, n_frames - ((n_frames - 1) / c->B) * c->B);
             c->last_frames = n_frames;
             c->pyramid_valid = true;
