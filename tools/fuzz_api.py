@@ -50,7 +50,7 @@ def main():
             fails += 0 if ok else 1
 
         for op in range(n_ops // 3):
-            kind = rng.choice(["host", "device", "device", "single", "match"])
+            kind = rng.choice(["host", "device", "device", "single", "match", "approx", "geometry"])
             ids = [int(i) for i in rng.integers(0, len(pool), int(rng.integers(1, 2 * B + 2)))]
             print("next: %s %s" % (kind, ids), flush=True)
             if kind == "host":
@@ -73,6 +73,31 @@ def main():
                 kps, counts = eng.detect(pool[i])
                 ds, dc = eng.describe(kps, counts)
                 check("detect+describe", (kps, counts[None], ds, dc[None]), [i])
+            elif kind == "approx":
+                i, j = ids[0], ids[-1]
+                m = eng.approximate_match(ref[i][2], ref[j][2])
+                want = pyoracle.approximate_match(ref[i][2]["features"].astype(np.int32), ref[j][2]["features"].astype(np.int32))
+                ok = np.array_equal(m["source"], want["source"]) and np.array_equal(m["target"], want["target"]) and \
+                    np.array_equal(m["distance"], want["distance"])
+                print("%s approximateMatch %d vs %d: %d matches" % ("ok  " if ok else "FAIL", i, j, len(m)), flush=True)
+                fails += 0 if ok else 1
+            elif kind == "geometry":
+                i, j = ids[0], ids[-1]
+                def xy(rec):            # absolute coordinates of each descriptor's keypoint (octave groups are concatenated)
+                    k, kc, d, dc = rec
+                    out, kp0, d0 = np.zeros((len(d), 2), np.float32), 0, 0
+                    for o in range(len(kc)):
+                        kk = k[kp0:kp0 + kc[o]]; dd = d[d0:d0 + dc[o]]
+                        out[d0:d0 + dc[o], 0] = kk["abs_x"][dd["keypoint"]]; out[d0:d0 + dc[o], 1] = kk["abs_y"][dd["keypoint"]]
+                        kp0 += kc[o]; d0 += dc[o]
+                    return out
+                axy, bxy = xy(ref[i]), xy(ref[j])
+                score, n = eng.match_geometry(ref[i][2], axy, ref[j][2], bxy)
+                mm = eng.match(ref[i][2], ref[j][2])
+                want = pyoracle.compare_geometry(mm[:80], axy, bxy) if len(mm) >= 7 else 0.0
+                ok = n == len(mm) and (score == want or (np.isnan(score) and np.isnan(want)) or abs(score - want) <= 1e-6 * abs(want))
+                print("%s matchGeometry %d vs %d: %d matches, score %.6f" % ("ok  " if ok else "FAIL", i, j, n, score), flush=True)
+                fails += 0 if ok else 1
             else:
                 i, j = ids[0], ids[-1]
                 m = eng.match(ref[i][2], ref[j][2])
