@@ -57,16 +57,18 @@ def main():
             max_oct += 1
         no = int(rng.integers(1, max_oct + 1))
         kind, img = make_image(rng, w, h)
-        tag = "case %d: %dx%d octaves %d nspo %d %s" % (case, w, h, no, nspo, kind)
+        # blur / extrema code path: default (tile blur, full scan), marching blur + flagged-row extrema scan, marching blur only
+        mode = [{}, {"blur_march_min_blocks": 1}, {"blur_march_min_blocks": 1, "count_raw_extrema": 1}][int(rng.integers(0, 3))]
+        tag = "case %d: %dx%d octaves %d nspo %d %s %s" % (case, w, h, no, nspo, kind, mode or "default")
         try:
             try:
-                r = parity.check_full_path(sm, img, no, nspo, strict_theta=False)
+                r = parity.check_full_path(sm, img, no, nspo, strict_theta=False, **mode)
             except sm.SiftmiError as e:
                 if "capacity" not in str(e):
                     raise
                 # dense synthetic patterns (checkerboards: 4 orientations per corner) overflow the default lists, which is a
                 # reported, recoverable condition: retry with explicit capacities
-                r = parity.check_full_path(sm, img, no, nspo, strict_theta=False, max_extrema=1 << 18, max_keypoints=1 << 17, max_descriptors=1 << 19)
+                r = parity.check_full_path(sm, img, no, nspo, strict_theta=False, max_extrema=1 << 18, max_keypoints=1 << 17, max_descriptors=1 << 19, **mode)
                 tag += " (raised capacities)"
             print("ok   %s -> %d keypoints" % (tag, r["keypoints"]), flush=True)
         except AssertionError as e:
