@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
             const size_t slot = (size_t)frame * P.kp_frame + P.kp_off[o] + s_base + li;
             kp_tmp[slot] = r;
             kp_keys[slot] = key;
-            atomicAdd(&row_count[(size_t)frame * P.row_frame + P.row_off[o] + (size_t)(r.scale * h + r.y)], 1);   // bucket sizes for the sort
+            if (row_count)                                                    // bucket sizes for the row-bucket sort (large launches)
+                atomicAdd(&row_count[(size_t)frame * P.row_frame + P.row_off[o] + (size_t)(r.scale * h + r.y)], 1);
         }
         __syncthreads();
     }
@@ -402,6 +403,30 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
 // source index) into the buckets in arbitrary order; kp_row_rank_kernel ranks every entry inside its bucket (a row holds
 // a handful of keypoints) and moves the record.  O(n + rows) instead of the O(n^2) of a plain rank sort, which took
 // 3.9 ms of a 13 ms 8192 x 8192 tile (50 k keypoints in one group).
+// Small launches (a frame or two): one rank-sort kernel instead of the four launches of the bucket sort below -- at ~20 us
+// per dependent launch the launch count is what a single frame pays for.  O(n^2) compares per group, n a few thousand.
+__global__ __launch_bounds__(256) void sort_keypoints_kernel(PyramidDesc P, const KeypointRec *__restrict__ kp_tmp,
+                                                            const unsigned long long *__restrict__ kp_keys,
+                                                            const int32_t *__restrict__ kp_count, KeypointRec *__restrict__ kp_sorted) {
+    __shared__ unsigned long long tile[1024];
+    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(kp_count[group], P.cap_kp[o]);
+    const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        const unsigned long long key = (i < n) ? kp_keys[base + i] : ~0ull;
+        int rank = 0;
+        for (int j0 = 0; j0 < n; j0 += 1024) {
+            __syncthreads();
+            for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = (j0 + j < n) ? kp_keys[base + j0 + j] : ~0ull;
+            __syncthreads();
+            const int m = min(1024, n - j0);
+            for (int j = 0; j < m; j++) rank += (tile[j] < key) ? 1 : 0;
+        }
+        if (i < n) kp_sorted[base + rank] = kp_tmp[base + i];
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t *__restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
 }

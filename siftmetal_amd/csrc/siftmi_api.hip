@@ -207,7 +207,7 @@ static void free_ctx(siftmi_ctx *c) {
     (void)hipDeviceSynchronize();             // nothing of this context may still be running when its memory and graphs go
     void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_bucket_keys, c->d_bucket_src, c->d_row_count,
                     c->d_row_start, c->d_act, c->d_ori_count, c->d_ori_angles,
-                    c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_state, c->d_out_kp,
+                    c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_out_kp,
                     c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out, c->d_match_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -349,9 +349,10 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     alloc((void **)&c->d_desc_in, B * desc_off * sizeof(DescInput));
     alloc((void **)&c->d_desc, B * desc_off * sizeof(DescriptorRec));
     if (cfg->keep_descriptor_floats) alloc((void **)&c->d_desc_f32, B * desc_off * DESC_N * sizeof(float));
-    alloc((void **)&c->d_counters, 5 * G * sizeof(int32_t));
+    alloc((void **)&c->d_counters, 5 * G * sizeof(int32_t) + sizeof(PackState));
+    if (e == hipSuccess) c->d_state = (PackState *)(c->d_counters + 5 * G);
     alloc((void **)&c->d_dst_off, 2 * G * sizeof(int32_t));
-    alloc((void **)&c->d_state, sizeof(PackState));
+    // d_state lives right behind the counters (same allocation) so that one kernel clears both at the start of a call
     if (e != hipSuccess) {
         const int code = (e == hipErrorOutOfMemory) ? SIFTMI_E_NOMEM : SIFTMI_E_HIP;
         set_error(code, "context allocation failed: %s", hipGetErrorString(e));
@@ -517,7 +518,7 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
 // stream while octave o+1 continues on another one; everything joins before refinement.  Large batches fill
 // the chip with every launch and gain nothing from this (tools/two_stream_probe.py), so they stay serial.
 static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d_pixels, int format, size_t row_stride, size_t frame_stride,
-                            bool fork) {
+                            bool fork, bool first_of_call) {
     const int NG = c->nspo + 3;
     int rc;
     if (fork && (rc = ensure_fork(c))) return rc;
@@ -528,7 +529,9 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     Decimate nodec; memset(&nodec, 0, sizeof(nodec));
     // Counters are cleared by a kernel, not hipMemsetAsync: memset nodes captured into the hipGraph stopped clearing from the
     // third launch of a serial graph on (ROCm 7.2; tests/test_gpu_parity.py::test_graph_replays_stay_correct).
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters, 5 * (size_t)c->B * c->n_oct);
+    // the first sub-batch of a call also clears the running totals (PackState) that sit behind the counters
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters,
+                       5 * (size_t)c->B * c->n_oct + (first_of_call ? sizeof(PackState) / sizeof(int32_t) : 0));
     t_begin(c, SIFTMI_T_SEED);
     HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed, nodec)));
     t_end(c);
@@ -570,18 +573,24 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
 // refine -> sort  (SIFT.swift:190-202)
 static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
     const int groups = nf * c->n_oct;
+    // a frame or two: the launch count matters more than the sort's complexity (see sort_keypoints_kernel)
+    const bool small = (long long)nf * c->ow[0] * c->oh[0] <= 16ll * 1024 * 1024;
     t_begin(c, SIFTMI_T_REFINE);
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
+    if (!small) hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
     hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
-                       cnt(c, C_KP), c->d_row_count);
+                       cnt(c, C_KP), small ? (int32_t *)nullptr : c->d_row_count);
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_SORT);
-    hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, c->P, c->d_row_count, c->d_row_start);
-    hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
-                       c->d_bucket_keys, c->d_bucket_src);
-    hipLaunchKernelGGL(kp_row_rank_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_bucket_keys, c->d_bucket_src, cnt(c, C_KP),
-                       c->d_row_start, c->d_row_count, c->d_kp);
+    if (small) {
+        hipLaunchKernelGGL(sort_keypoints_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_keys, cnt(c, C_KP), c->d_kp);
+    } else {
+        hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, c->P, c->d_row_count, c->d_row_start);
+        hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
+                           c->d_bucket_keys, c->d_bucket_src);
+        hipLaunchKernelGGL(kp_row_rank_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_bucket_keys, c->d_bucket_src, cnt(c, C_KP),
+                           c->d_row_start, c->d_row_count, c->d_kp);
+    }
     HIP_TRY(hipGetLastError());
     t_end(c);
     return SIFTMI_OK;
@@ -662,11 +671,10 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
                          int32_t *d_counts, int32_t *d_totals, bool fork) {
     int rc;
     c->tstream = st;
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t *)c->d_state, sizeof(PackState) / sizeof(int32_t));
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
-        if ((rc = run_dense_detect(c, st, nf, px, format, row_stride, frame_stride, fork))) return rc;
+        if ((rc = run_dense_detect(c, st, nf, px, format, row_stride, frame_stride, fork, f0 == 0))) return rc;
         if ((rc = run_refine(c, st, nf))) return rc;
         if ((rc = run_describe(c, st, nf))) return rc;
         if ((rc = run_pack(c, st, nf, f0, n_frames, d_kp, kp_cap, d_desc, desc_cap, d_counts, c->d_stats))) return rc;
@@ -834,13 +842,12 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     if ((rc = ensure_stats(c, n_frames))) return rc;
     hipStream_t st = c->stream;
     c->tstream = st;
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t *)c->d_state, sizeof(PackState) / sizeof(int32_t));
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const void *d_px; size_t d_row, d_frame;
         const unsigned char *src = (const unsigned char *)pixels + (size_t)f0 * frame_stride;
         if ((rc = stage_input(c, nf, src, format, row_stride, frame_stride, on_device, &d_px, &d_row, &d_frame))) return rc;
-        if ((rc = run_dense_detect(c, st, nf, d_px, format, d_row, d_frame, false))) return rc;
+        if ((rc = run_dense_detect(c, st, nf, d_px, format, d_row, d_frame, false, f0 == 0))) return rc;
         if ((rc = input_consumed(c, on_device))) return rc;
         if ((rc = run_refine(c, st, nf))) return rc;
         if ((rc = run_describe(c, st, nf))) return rc;
@@ -881,7 +888,7 @@ extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size
     c->tstream = st;
     const void *d_px; size_t d_row, d_frame;
     if ((rc = stage_input(c, 1, pixels, format, row_stride, 0, on_device, &d_px, &d_row, &d_frame))) return rc;
-    if ((rc = run_dense_detect(c, st, 1, d_px, format, d_row, d_frame, false))) return rc;
+    if ((rc = run_dense_detect(c, st, 1, d_px, format, d_row, d_frame, false, true))) return rc;
     if ((rc = input_consumed(c, on_device))) return rc;
     if ((rc = run_refine(c, st, 1))) return rc;
     std::vector<int32_t> h(5 * (size_t)c->B * c->n_oct);
