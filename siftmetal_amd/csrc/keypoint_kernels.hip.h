@@ -390,8 +390,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
             const size_t slot = (size_t)frame * P.kp_frame + P.kp_off[o] + s_base + li;
             kp_tmp[slot] = r;
             kp_keys[slot] = key;
-            if (row_count)                                                    // bucket sizes for the row-bucket sort (large launches)
-                atomicAdd(&row_count[(size_t)frame * P.row_frame + P.row_off[o] + (size_t)(r.scale * h + r.y)], 1);
+            atomicAdd(&row_count[(size_t)frame * P.row_frame + P.row_off[o] + (size_t)(r.scale * h + r.y)], 1);   // bucket sizes for the sort
         }
         __syncthreads();
     }
@@ -403,30 +402,6 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
 // source index) into the buckets in arbitrary order; kp_row_rank_kernel ranks every entry inside its bucket (a row holds
 // a handful of keypoints) and moves the record.  O(n + rows) instead of the O(n^2) of a plain rank sort, which took
 // 3.9 ms of a 13 ms 8192 x 8192 tile (50 k keypoints in one group).
-// Small launches (a frame or two): one rank-sort kernel instead of the four launches of the bucket sort below -- at ~20 us
-// per dependent launch the launch count is what a single frame pays for.  O(n^2) compares per group, n a few thousand.
-__global__ __launch_bounds__(256) void sort_keypoints_kernel(PyramidDesc P, const KeypointRec *__restrict__ kp_tmp,
-                                                            const unsigned long long *__restrict__ kp_keys,
-                                                            const int32_t *__restrict__ kp_count, KeypointRec *__restrict__ kp_sorted) {
-    __shared__ unsigned long long tile[1024];
-    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
-    const int n = min(kp_count[group], P.cap_kp[o]);
-    const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-        const int i = i0 + threadIdx.x;
-        const unsigned long long key = (i < n) ? kp_keys[base + i] : ~0ull;
-        int rank = 0;
-        for (int j0 = 0; j0 < n; j0 += 1024) {
-            __syncthreads();
-            for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = (j0 + j < n) ? kp_keys[base + j0 + j] : ~0ull;
-            __syncthreads();
-            const int m = min(1024, n - j0);
-            for (int j = 0; j < m; j++) rank += (tile[j] < key) ? 1 : 0;
-        }
-        if (i < n) kp_sorted[base + rank] = kp_tmp[base + i];
-    }
-}
-
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t *__restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
 }
@@ -680,6 +655,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// COOP = false: one wavefront per descriptor (large launches: there are more descriptors than wavefronts in flight).
+// COOP = true: the four wavefronts of a workgroup share one descriptor -- for a frame or two there are fewer descriptors than
+// wavefront slots, and a descriptor's ~3000 samples walked by 64 lanes take 60-100 us of dependent loads and LDS atomics;
+// four waves cut that to a quarter.  Same samples into the same u64 fixed-point bins, so the result is bit-identical.
+template <bool COOP>
 __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
@@ -693,8 +673,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
     __shared__ int col_start_all[4][MAXCOL + 1];
     __shared__ short col_lo_all[4][MAXCOL];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long *patch = patch_all[wv][lane & (NCOPY - 1)];
-    unsigned long long *patch0 = patch_all[wv][0];
+    const int hw_ = COOP ? 0 : wv;                          // whose histogram copies: the workgroup's (COOP) or this wave's
+    constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
+    const int lidx = COOP ? (int)threadIdx.x : lane;
+    unsigned long long *patch = patch_all[hw_][lane & (NCOPY - 1)];
+    unsigned long long *patch0 = patch_all[hw_][0];
     int *col_start = col_start_all[wv];
     short *col_lo = col_lo_all[wv];
     const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
@@ -703,7 +686,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
     const float delta = P.delta[o];
     const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
     const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
-    for (int di = blockIdx.x * 4 + wv; di < n; di += gridDim.x * 4) {
+    for (int di = COOP ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wv); di < n; di += COOP ? (int)gridDim.x : (int)(gridDim.x * 4)) {
         const DescInput in = desc_in[dbase + di];
         const KeypointRec kp = kps[kbase + in.keypoint];
         const float theta = in.theta;
@@ -722,8 +705,13 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
         const float histogramWidth = 3.0f * sc;
         const int radius = (int)(histogramWidth * sqrtf(2.0f) * ((float)d + 1.0f) * 0.5f + 0.5f);
 
+        if (COOP) {
+            __syncthreads();                                                          // wave 0 is done reading the previous descriptor's bins
+            for (int c = threadIdx.x; c < NCOPY * DESC_N; c += 256) patch0[c] = 0ull;
+        } else {
 #pragma unroll
-        for (int c = 0; c < NCOPY * DESC_N / 64; c++) patch0[c * 64 + lane] = 0ull;   // all copies (contiguous)
+            for (int c = 0; c < NCOPY * DESC_N / 64; c++) patch0[c * 64 + lane] = 0ull;   // all copies (contiguous)
+        }
         const int side = 2 * radius + 1;
 
         // The reference visits every (j, i) of the (2 radius + 1)^2 window (metal :194-195), but a sample adds
@@ -767,17 +755,17 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
         } else {
             total = side * side;
         }
-        __builtin_amdgcn_wave_barrier();
+        if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // bins cleared (COOP: by all four waves); column table of this wave written
         __threadfence_block();
 
         int cur = 0;                                                       // column of this lane's current sample
-        if (compact && lane < total) {                                     // binary search once, then only advance
-            int lo_c = 0, hi_c = side - 1;                                 // last column whose start <= lane
-            while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= lane) lo_c = mid; else hi_c = mid - 1; }
+        if (compact && lidx < total) {                                     // binary search once, then only advance
+            int lo_c = 0, hi_c = side - 1;                                 // last column whose start <= lidx
+            while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= lidx) lo_c = mid; else hi_c = mid - 1; }
             cur = lo_c;
         }
         int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
-        for (int idx = lane; idx < total; idx += 64) {
+        for (int idx = lidx; idx < total; idx += STRIDE) {
             int j, i;                                                      // j: x offset (outer), i: y offset (inner)
             if (compact) {
                 while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty columns have equal starts
@@ -822,7 +810,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
                 add_value(patch, cax, ccy, bb, (iMin * jMax * bMax) * value);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
         __threadfence_block();
         unsigned long long a0 = patch0[lane], a1 = patch0[64 + lane];
 #pragma unroll

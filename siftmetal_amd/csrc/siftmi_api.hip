@@ -573,24 +573,18 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
 // refine -> sort  (SIFT.swift:190-202)
 static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
     const int groups = nf * c->n_oct;
-    // a frame or two: the launch count matters more than the sort's complexity (see sort_keypoints_kernel)
-    const bool small = (long long)nf * c->ow[0] * c->oh[0] <= 16ll * 1024 * 1024;
     t_begin(c, SIFTMI_T_REFINE);
-    if (!small) hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
     hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
-                       cnt(c, C_KP), small ? (int32_t *)nullptr : c->d_row_count);
+                       cnt(c, C_KP), c->d_row_count);
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_SORT);
-    if (small) {
-        hipLaunchKernelGGL(sort_keypoints_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_keys, cnt(c, C_KP), c->d_kp);
-    } else {
-        hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, c->P, c->d_row_count, c->d_row_start);
-        hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
-                           c->d_bucket_keys, c->d_bucket_src);
-        hipLaunchKernelGGL(kp_row_rank_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_bucket_keys, c->d_bucket_src, cnt(c, C_KP),
-                           c->d_row_start, c->d_row_count, c->d_kp);
-    }
+    hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, c->P, c->d_row_count, c->d_row_start);
+    hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
+                       c->d_bucket_keys, c->d_bucket_src);
+    hipLaunchKernelGGL(kp_row_rank_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_bucket_keys, c->d_bucket_src, cnt(c, C_KP),
+                       c->d_row_start, c->d_row_count, c->d_kp);
     HIP_TRY(hipGetLastError());
     t_end(c);
     return SIFTMI_OK;
@@ -608,8 +602,13 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf) {
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_DESCRIBE);
-    hipLaunchKernelGGL(descriptor_kernel, dim3(256, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
-                       c->d_desc_f32);
+    // a frame or two: fewer descriptors than wavefront slots -> one workgroup per descriptor (see descriptor_kernel)
+    if ((long long)nf * c->ow[0] * c->oh[0] <= 16ll * 1024 * 1024)
+        hipLaunchKernelGGL(descriptor_kernel<true>, dim3(1024, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+                           c->d_desc_f32);
+    else
+        hipLaunchKernelGGL(descriptor_kernel<false>, dim3(256, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+                           c->d_desc_f32);
     HIP_TRY(hipGetLastError());
     t_end(c);
     return SIFTMI_OK;
