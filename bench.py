@@ -203,8 +203,7 @@ def main():
                 ratio = sum(k["hbm_bytes_per_launch_corrected"] for k in ks) / (pj["algorithmic_bytes_per_launch"] * len(ks))
                 traffic = int(ratio * total_bytes / max(blur_n, 1))
                 traffic_src = ("profiles/%s: PMC bytes / algorithmic bytes = %.3f averaged over the five octave-0 layer launches "
-                               "(1.06-1.10 for the plain ones; ~1.4-1.6 for the three that re-read their input layer to write the extrema "
-                               "activity flags, which removes 3/4 of the extrema scan's reads), scaled to the average launch" % (prof[-1], ratio))
+                               "(the one with the fused decimation output writes 1.06x more), scaled to the average launch" % (prof[-1], ratio))
         out["roofline"] = {"bound": "hbm", "kernel": "blur2_kernel<R> / blur_march_kernel<R> (one Gaussian layer, fused X+Y)", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "traffic_source": traffic_src,

@@ -424,7 +424,7 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
             march = true;
             dim3 grid(((total + 7) / 8) * 8, 1, 1);
             if (act.dst)
-                hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC, false, 256, 0, 128, 4, true>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h,
+                hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC, false, 256, 0, 128, 4, true>), grid, dim3(Gm::NTHR), Gm::lds_bytes_act, st, src, dst, w, h,
                                    c->frame_stride, c->frame_stride, wt, nf, spc, dec, act);
             else
                 hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
