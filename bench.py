@@ -11,16 +11,26 @@ octave), frames already resident in HBM, results left in HBM; with N > 1 every r
 64 frames (frame-per-GPU sharding, weak scaling) and the step ends with the RCCL all-gather of the
 descriptor buffers.  Rank 0 prints ONE JSON line.
 
+`--gpus N` with N > 1 and no torchrun environment: this process spawns the N ranks itself (before any
+GPU call) and relays rank 0's line; it exits non-zero if fewer than N devices are visible or the
+process group does not come up with N ranks.
+
 Extra objects in the line:
   roofline     Gaussian-layer blur kernel (the "pyramid kernel"): algorithmic bytes (8 B per octave
                pixel per layer) / average launch duration measured with hipEvents on the
                launch stream in a second, identical, event-instrumented pass of K steps.
   cpu_baseline the CPU oracle (a port of the reference's algorithm; kind "port") timed on the host
-               cores on a bounded sample of the same frames.
+               cores on a bounded sample of the same frames: all cores, and one thread.
+  config.single_frame / config.host_io / config.dense
+               BASELINE configs[1] (one frame per call), the same 64-frame step fed from pinned host
+               memory with the packed results copied back (PCIe-inclusive; never `value`), and the
+               step on 64 dense natural-texture frames (mirror-tiled butterfly, ~7x the keypoints).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +42,7 @@ import numpy as np  # noqa: E402
 
 W, H, N_OCT, NSPO = 1920, 1080, 4, 3
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_COPY_GBS = 6290.0          # same guide: measured float4 copy rate
 
 
 def log(*a):
@@ -45,20 +56,76 @@ def make_frames(n, distinct):
     return np.stack([base[i % len(base)] for i in range(n)])
 
 
-def cpu_baseline(frames, seconds_budget=20.0):
-    """Times the oracle (oracle/sift_oracle.c, OpenMP) on a bounded sample of the same frames."""
+def make_dense_frames(n):
+    """SURVEY.md 8d 'dense stress variant': the reference's test image mirror-tiled to 1920x1080; frame i is the mosaic
+    rolled by 16 i columns so that the frames differ."""
+    from PIL import Image
+    im = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "butterfly.png")))
+    b = np.ascontiguousarray(im[..., [2, 1, 0, 3]])
+    row = np.concatenate([b, b[:, ::-1], b, b[:, ::-1]], axis=1)
+    full = np.ascontiguousarray(np.concatenate([row, row[::-1], row, row[::-1]], axis=0)[:H, :W])
+    return np.stack([np.roll(full, 16 * (i % 8), axis=1) for i in range(n)])
+
+
+def cpu_baseline(frames, seconds_budget=18.0):
+    """Times the oracle (oracle/sift_oracle.c, OpenMP) on a bounded sample of the same frames: all cores, then 1 thread."""
     from oracle import pyoracle
     orc = pyoracle.Oracle(W, H, n_octaves=N_OCT, nspo=NSPO)
-    t0 = time.time()
-    done = 0
-    n_desc = 0
-    while done < len(frames) and (done == 0 or (time.time() - t0) * (done + 1) / done < seconds_budget):
-        tot, _ = orc.detect_describe_counts(frames[done])
-        n_desc += tot
-        done += 1
-    dt = time.time() - t0
-    return {"value": round(done * W * H / dt / 1e6, 4), "unit": "Mpixels/s", "cores": pyoracle.num_threads(), "kind": "port",
-            "sample": "%d x %dx%d synthetic frames (same generator), %d octaves, %.1f s, %d descriptors" % (done, W, H, N_OCT, dt, n_desc)}
+
+    def run(budget, max_frames):
+        t0 = time.time()
+        done = n_desc = 0
+        while done < min(len(frames), max_frames) and (done == 0 or (time.time() - t0) * (done + 1) / done < budget):
+            tot, _ = orc.detect_describe_counts(frames[done])
+            n_desc += tot
+            done += 1
+        return done, n_desc, time.time() - t0
+
+    cores = pyoracle.num_threads()
+    done, n_desc, dt = run(seconds_budget, len(frames))
+    out = {"value": round(done * W * H / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+           "sample": "%d x %dx%d synthetic frames (same generator), %d octaves, %.1f s, %d descriptors" % (done, W, H, N_OCT, dt, n_desc)}
+    pyoracle.set_num_threads(1)
+    done1, n_desc1, dt1 = run(0.0, 1)                       # one frame: 10-30 s on one core
+    pyoracle.set_num_threads(cores)
+    out["single_thread"] = {"value": round(done1 * W * H / dt1 / 1e6, 4), "unit": "Mpixels/s", "cores": 1,
+                            "sample": "%d frame, %.1f s, %d descriptors" % (done1, dt1, n_desc1)}
+    return out
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: spawn the ranks (no GPU call has happened in this process)."""
+    import torch
+    n_dev = torch.cuda.device_count()                      # does not initialise the GPU runtime
+    if n_dev < args.gpus:
+        print("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, n_dev), file=sys.stderr)
+        return 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        print("bench.py: the %d-rank launch failed (exit code %d, %d JSON lines)" % (args.gpus, p.returncode, len(lines)), file=sys.stderr)
+        return p.returncode or 4
+    print(lines[-1], flush=True)
+    return 0
+
+
+def timed_steps(step, barrier, steps, warmup):
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -71,7 +138,11 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (cycled to fill the batch)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip single_frame / host_io / dense")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     # Library chatter (e.g. RCCL's version banner at communicator init) must not reach stdout: the
     # contract is ONE JSON line.  Point fd 1 at stderr for the run and restore it for the final print.
@@ -85,20 +156,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: local rank %d but only %d HIP device(s) visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # SIFTMI_FORCE_GATHER=1 exercises the RCCL exchange with a single rank (smoke test on a 1-GPU box)
     force_gather = os.environ.get("SIFTMI_FORCE_GATHER") == "1" and "RANK" in os.environ
-    if world > 1 or force_gather:
+    use_dist = world > 1 or force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != world:
+            raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
 
     import __graft_entry__ as ge
-    ge.build()
+    if local_rank == 0:                                     # one build per node; the others load the finished library
+        ge.build()
+    if use_dist:
+        dist.barrier()
     import siftmetal_amd as sm
     from siftmetal_amd import stream as smstream
 
@@ -115,29 +194,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gather_ev = []
+
     def step():
         runner.run(d_frames)
-        if world > 1 or force_gather:
+        if use_dist:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
             runner.all_gather()
+            b.record()
+            gather_ev.append((a, b))
 
     # reference counts from one synchronised step; every later step (graph replays included) must reproduce them
     step()
     barrier()
     first = runner.results_host()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    gather_ev.clear()
+    dt = timed_steps(step, barrier, args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * F * W * H * args.steps / dt / 1e6
+    gather_ms = None
+    if use_dist:
+        incomplete, overflowed = runner.exchange.finish()
+        if incomplete or overflowed:
+            raise SystemExit("bench: all-gather payloads were undersized in steps %s / list overflow in steps %s" % (incomplete, overflowed))
+        gather_ms = sum(a.elapsed_time(b) for a, b in gather_ev[-args.steps:]) / args.steps
 
     res = runner.results_host()
     if (res["n_keypoints"], res["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]) or \
@@ -155,6 +240,8 @@ def main():
                                   "detect+describe, frames and results resident in HBM%s" %
                                   (F, N_OCT, NSPO, ", RCCL all-gather of descriptors" if world > 1 else ""),
                       "frames_per_gpu": F, "lockstep_batch": eng.max_batch, "parallelism": "frame-per-GPU x%d" % world,
+                      "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                      "all_gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4),
                       "keypoints_per_step_rank0": res["n_keypoints"], "descriptors_per_step_rank0": res["n_descriptors"]}}
 
     if rank == 0 and not args.no_roofline:
@@ -182,36 +269,25 @@ def main():
         # HBM bytes per launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/profile_round.sh)
         traffic, traffic_src = None, None
-        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("blur_hbm_traffic_")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        pdir = os.path.join(ROOT, "profiles")
+        prof = sorted(f for f in os.listdir(pdir) if f.startswith("blur_hbm_traffic_")) if os.path.isdir(pdir) else []
         if prof:
-            pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-            import re
-            # the five octave-0 layer launches of this pipeline: radius from the schedule; layer nspo carries the fused
-            # decimation output (DEC), layers 2 ... nspo+1 write the extrema activity flags (ACT, re-reads its input layer)
-            def find(radius, dec, act):
-                for k in pj["kernels"]:
-                    m = re.search(r"march_kernel<(\d+), \d+, \d+, (true|false), (?:true|false), \d+, \d+, \d+, \d+, (true|false)>", k["kernel"])
-                    if m and int(m.group(1)) == radius and (m.group(2) == "true") == dec and (m.group(3) == "true") == act:
-                        return k
-                return None
-            ks = []
-            for layer in range(1, NSPO + 3):
-                k = find(len(eng.weights(layer)) // 2, layer == NSPO, 2 <= layer <= NSPO + 1)
-                if k:
-                    ks.append(k)
+            pj = json.load(open(os.path.join(pdir, prof[-1])))
+            ks = [k for k in pj.get("kernels", []) if k.get("pipeline_layer")]
             if len(ks) == NSPO + 2:
                 ratio = sum(k["hbm_bytes_per_launch_corrected"] for k in ks) / (pj["algorithmic_bytes_per_launch"] * len(ks))
                 traffic = int(ratio * total_bytes / max(blur_n, 1))
-                traffic_src = ("profiles/%s: PMC bytes / algorithmic bytes = %.3f averaged over the five octave-0 layer launches "
-                               "(the one with the fused decimation output writes 1.06x more), scaled to the average launch" % (prof[-1], ratio))
-        out["roofline"] = {"bound": "hbm", "kernel": "blur2_kernel<R> / blur_march_kernel<R> (one Gaussian layer, fused X+Y)", "achieved": round(achieved, 1),
+                traffic_src = ("profiles/%s: PMC bytes / algorithmic bytes = %.3f averaged over the five octave-0 layer launches of the "
+                               "pipeline, scaled to the average launch" % (prof[-1], ratio))
+        out["roofline"] = {"bound": "hbm", "kernel": "blur_ring_kernel<R> (large launches) / blur2_kernel<R> (small octaves): one Gaussian layer, fused X+Y",
+                           "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "traffic_source": traffic_src,
+                           "traffic_source": traffic_src, "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBS, 4),
                            "launches": blur_n, "avg_launch_ms": round(blur_ms / max(blur_n, 1), 5),
                            "algorithmic_bytes_per_launch_avg": int(total_bytes / max(blur_n, 1)),
                            "octave0_GBps_by_layer": per_layer, "stage_ms_per_step": stage_ms,
                            "measured_in": "second identical pass of K steps, hipEvents around every launch on the launch stream"}
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         # BASELINE configs[1]: ONE 1920x1080 frame per call (lock-step batch 1, hipGraph replay), frame in HBM
         e1 = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=1)
         r1 = smstream.FrameStream(e1, 1, device=dev)
@@ -229,6 +305,43 @@ def main():
                                          "Mpixels_per_s": round(W * H / ms1 / 1e3, 1)}
         log("single frame: %.3f ms (%.0f Mpixels/s)" % (ms1, W * H / ms1 / 1e3))
         del r1, e1
+        # the metric as SURVEY.md 8d words it: frames cross PCIe from pinned host memory, packed results are copied back
+        pin = sm.pinned_empty(frames_np.shape, np.uint8)
+        pin[...] = frames_np
+        eng.detect_describe_batch(pin, copy=False)
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            k, kc, d, dc = eng.detect_describe_batch(pin, copy=False)
+        ms_io = (time.perf_counter() - t1) / reps * 1e3
+        out["config"]["host_io"] = {"workload": "the same %d-frame step through siftmi_detect_describe_batch: BGRA8 frames in pinned host memory "
+                                                "(H2D copy of sub-batch i+1 under the kernels of sub-batch i), packed keypoints + descriptors copied back" % F,
+                                    "ms_per_step": round(ms_io, 4), "Mpixels_per_s": round(F * W * H / ms_io / 1e3, 1),
+                                    "h2d_bytes_per_step": int(pin.nbytes), "d2h_bytes_per_step": int(k.nbytes + d.nbytes),
+                                    "keypoints": int(len(k)), "descriptors": int(len(d))}
+        log("host i/o step: %.3f ms (%.0f Mpixels/s)" % (ms_io, F * W * H / ms_io / 1e3))
+        del k, d
+        sm.pinned_release(pin)
+        # dense natural texture: the same step on 64 mirror-tiled butterfly frames (not sparse synthetic blobs)
+        d_dense = torch.from_numpy(make_dense_frames(F)).to(dev)
+        runner.run(d_dense)
+        torch.cuda.synchronize()
+        dres = runner.results_host()
+        dt_d = timed_steps(lambda: runner.run(d_dense), torch.cuda.synchronize, args.steps, 1)
+        ms_d = dt_d / args.steps * 1e3
+        out["config"]["dense"] = {"workload": "%d x 1920x1080 mirror-tiled butterfly frames (SURVEY.md 8d dense variant), resident in HBM" % F,
+                                  "ms_per_step": round(ms_d, 4), "Mpixels_per_s": round(F * W * H / ms_d / 1e3, 1),
+                                  "keypoints_per_step": dres["n_keypoints"], "descriptors_per_step": dres["n_descriptors"]}
+        log("dense step: %.3f ms (%.0f Mpixels/s), %d keypoints, %d descriptors" % (ms_d, F * W * H / ms_d / 1e3, dres["n_keypoints"], dres["n_descriptors"]))
+        if not args.no_roofline:
+            eng.enable_timings(True)
+            eng.reset_timings()
+            for _ in range(args.steps):
+                runner.run(d_dense)
+            torch.cuda.synchronize()
+            out["config"]["dense"]["stage_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in eng.timings().items()}
+            eng.enable_timings(False)
+        del d_dense
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(frames_np)
     sys.stdout.flush()
@@ -236,7 +349,7 @@ def main():
     os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1 or force_gather:
+    if use_dist:
         dist.destroy_process_group()
 
 

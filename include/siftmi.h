@@ -134,6 +134,10 @@ typedef struct siftmi_stats {
     const int32_t *keypoints;
     const int32_t *oriented;            /* keypoints passing the orientation border filter         */
     const int32_t *descriptors;
+    int32_t raw_extrema_exact;          /* 1: raw_extrema counts every strict extremum, like the reference's counter;
+                                           0: the extrema scan skipped rows the blur flagged inactive (count_raw_extrema = 0
+                                           on a large launch), so raw_extrema counts the tested rows only.  candidates,
+                                           keypoints, oriented and descriptors are exact either way. */
 } siftmi_stats;
 
 typedef struct siftmi_ctx siftmi_ctx;
@@ -169,8 +173,13 @@ int siftmi_detect_describe_batch(siftmi_ctx *ctx, int32_t n_frames, const void *
 
 /* Same, everything staying in HBM (input and output are device pointers supplied by the caller,
    e.g. torch tensors that a following RCCL all-gather reads).  d_counts receives
-   [2][n_frames][n_octaves] int32 (keypoints, then descriptors); d_totals receives {n_kp, n_desc}.
-   Asynchronous on `stream` (a hipStream_t, NULL = the context's stream); no host sync. */
+   [2][n_frames][n_octaves] int32 (keypoints, then descriptors); d_totals receives FOUR int32:
+   {n_kp, n_desc, overflow_flags, 0}.  overflow_flags != 0 means a list was truncated (bit 0 max_extrema, 1 max_keypoints,
+   2 max_descriptors, 3 kp_capacity, 4 desc_capacity) -- the condition the host-facing entry points report as
+   SIFTMI_E_CAPACITY; the results that fit are valid.
+   Asynchronous on `stream` (a hipStream_t, NULL = the context's stream); no host sync.  The context's scratch is shared by
+   all entry points: a following call on this context (any entry point, any stream) is ordered after this one on the
+   device, and the introspection calls wait for it. */
 int siftmi_detect_describe_batch_device(siftmi_ctx *ctx, int32_t n_frames, const void *d_pixels, int format,
                                         size_t row_stride, size_t frame_stride,
                                         siftmi_keypoint *d_keypoints, int64_t kp_capacity,
@@ -227,6 +236,10 @@ int siftmi_get_sigma(siftmi_ctx *ctx, int octave, int scale, float *sigma);
 int siftmi_get_weights(siftmi_ctx *ctx, int layer /*0 = seed, 1..nspo+2*/, float *weights, int32_t *count);
 /* Gaussian layer G[octave][layer] of `frame` (of the last sub-batch) -> host, dense [h][w] f32 */
 int siftmi_copy_gaussian(siftmi_ctx *ctx, int frame, int octave, int layer, float *dst);
+/* DoG layer D[octave][scale] = G[scale + 1] - G[scale], scale < nspo + 2 -> host, dense [h][w] f32: the texture the
+   reference's DifferenceOfGaussians exposes (SIFT/DifferenceOfGaussians.swift:20, 346-406; Metal/Subtract.metal:12-21)
+   and DifferenceOfGaussiansTests.swift:15-270 diffs against DoG_butterfly_o*_s*.png */
+int siftmi_copy_dog(siftmi_ctx *ctx, int frame, int octave, int scale, float *dst);
 /* candidate list of (frame, octave), sorted by (scale, y, x) on the host */
 int siftmi_copy_extrema(siftmi_ctx *ctx, int frame, int octave, siftmi_extremum *dst, int32_t cap, int32_t *count);
 int siftmi_copy_orientations(siftmi_ctx *ctx, int frame, int octave, siftmi_orientation *dst, int32_t cap, int32_t *count);

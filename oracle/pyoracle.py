@@ -309,3 +309,7 @@ def approximate_match(src_features, tgt_features, absolute_threshold=300.0, rela
 
 def num_threads():
     return lib().so_num_threads()
+
+
+def set_num_threads(n):
+    lib().so_set_num_threads(int(n))

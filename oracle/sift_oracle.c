@@ -57,6 +57,15 @@ int so_num_threads(void) {
 #endif
 }
 
+/* n >= 1: number of OpenMP threads used by later calls (bench.py times the port on 1 thread and on all cores) */
+void so_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Sources/MetalShaders/Metal/Common.hpp:15-22  symmetrizedCoordinates
  * (C '%' truncates like MSL's, so i can stay negative for |i| > 2l: the read is then OOB -> 0) */

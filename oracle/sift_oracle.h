@@ -139,6 +139,7 @@ int so_approximate_match(const int32_t *src, int n_src, const int32_t *tgt, int 
                          so_match_rec *out, int cap);
 
 int so_num_threads(void);
+void so_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

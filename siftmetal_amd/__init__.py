@@ -10,7 +10,9 @@ All compute happens in libsiftmi.so (hand-written HIP for gfx950, C ABI in inclu
 module only binds it.  There is no CPU fallback: importing works anywhere, creating a SIFT object
 without a HIP device raises.
 """
+import atexit
 import ctypes as C
+import weakref
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
@@ -85,38 +87,48 @@ def _fmt_of(img):
     raise ValueError("image must be HxWx4 uint8 (BGRA, the reference's .bgra8Unorm), HxW uint8 or HxW float32")
 
 
-class _PinnedBuffer:
-    def __init__(self, nbytes):
-        self.ptr = C.c_void_p()
-        _capi.check(_capi.load().siftmi_host_alloc(nbytes, C.byref(self.ptr)))
-        self.nbytes = nbytes
+_interpreter_exiting = False
 
-    def __del__(self):
-        try:
-            if self.ptr:
-                _capi.load().siftmi_host_free(self.ptr)
-                self.ptr = None
-        except Exception:
-            pass
+
+def _mark_exit():
+    global _interpreter_exiting
+    _interpreter_exiting = True
+
+
+atexit.register(_mark_exit)
+
+
+def _free_pinned(addr):
+    # at interpreter teardown the HIP runtime may already be gone: leave the pages to process exit
+    if _interpreter_exiting:
+        return
+    try:
+        _capi.load().siftmi_host_free(C.c_void_p(addr))
+    except Exception:
+        pass
 
 
 def pinned_empty(shape, dtype=np.uint8):
     """numpy array over page-locked host memory (siftmi_host_alloc): frames stored here cross PCIe asynchronously at
-    the full link rate when passed to the batch API.  The memory lives as long as the array (and its views)."""
+    the full link rate when passed to the batch API.  The memory is freed when the array and every view of it are gone
+    (the ctypes block that backs them carries a finalizer), or at once by pinned_release."""
     dtype = np.dtype(dtype)
-    n = int(np.prod(shape)) * dtype.itemsize
-    buf = _PinnedBuffer(max(n, 1))
-    arr = np.ctypeslib.as_array(C.cast(buf.ptr, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].view(dtype).reshape(shape)
-    _pinned_owner[arr.ctypes.data] = buf     # keep-alive keyed by address; dropped by pinned_release or at exit
-    return arr
-
-
-_pinned_owner = {}
+    n = max(int(np.prod(shape)) * dtype.itemsize, 1)
+    ptr = C.c_void_p()
+    _capi.check(_capi.load().siftmi_host_alloc(n, C.byref(ptr)))
+    block = (C.c_uint8 * n).from_address(ptr.value)      # numpy keeps `block` alive as the base of the array and its views
+    block._siftmi_finalizer = weakref.finalize(block, _free_pinned, ptr.value)
+    return np.frombuffer(block, dtype=np.uint8, count=int(np.prod(shape)) * dtype.itemsize).view(dtype).reshape(shape)
 
 
 def pinned_release(arr):
-    """Free a pinned_empty array's memory now (the array must not be used afterwards)."""
-    _pinned_owner.pop(arr.ctypes.data, None)
+    """Free a pinned_empty array's memory now (the array and its views must not be used afterwards)."""
+    base = arr
+    while getattr(base, "base", None) is not None:
+        base = base.base
+    fin = getattr(getattr(base, "obj", base), "_siftmi_finalizer", None)
+    if fin is not None:
+        fin()
 
 
 class Engine:
@@ -247,13 +259,22 @@ class Engine:
         s = _capi.Stats()
         _capi.check(self.L.siftmi_get_stats(self.h, C.byref(s)))
         shape = (s.n_frames, s.n_octaves)
-        return {k: np.ctypeslib.as_array(getattr(s, k), shape=shape).copy()
-                for k in ("raw_extrema", "candidates", "keypoints", "oriented", "descriptors")}
+        out = {k: np.ctypeslib.as_array(getattr(s, k), shape=shape).copy()
+               for k in ("raw_extrema", "candidates", "keypoints", "oriented", "descriptors")}
+        out["raw_extrema_exact"] = bool(s.raw_extrema_exact)
+        return out
 
     def gaussian(self, o, s, frame=0):
         w, h, _ = self.octave_size(o)
         out = np.empty((h, w), np.float32)
         _capi.check(self.L.siftmi_copy_gaussian(self.h, frame, o, s, out.ctypes.data))
+        return out
+
+    def dog(self, o, s, frame=0):
+        """DoG layer D[o][s] = G[s + 1] - G[s] (the reference's DifferenceOfGaussians textures)."""
+        w, h, _ = self.octave_size(o)
+        out = np.empty((h, w), np.float32)
+        _capi.check(self.L.siftmi_copy_dog(self.h, frame, o, s, out.ctypes.data))
         return out
 
     def extrema(self, o, frame=0):

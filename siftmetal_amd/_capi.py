@@ -16,7 +16,7 @@ EXPORTS = [
     "siftmi_default_config", "siftmi_create", "siftmi_destroy", "siftmi_last_error", "siftmi_device_count",
     "siftmi_detect", "siftmi_describe", "siftmi_detect_describe_batch", "siftmi_detect_describe_batch_device",
     "siftmi_descriptor_to_reference", "siftmi_host_alloc", "siftmi_host_free", "siftmi_match_descriptors", "siftmi_approximate_match", "siftmi_match_geometry", "siftmi_descriptor_index", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
-    "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_extrema", "siftmi_copy_orientations",
+    "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_dog", "siftmi_copy_extrema", "siftmi_copy_orientations",
     "siftmi_copy_descriptor_floats", "siftmi_enable_timings", "siftmi_reset_timings", "siftmi_get_timings",
     "siftmi_blur_algorithmic_bytes", "siftmi_time_blur", "siftmi_synchronize",
 ]
@@ -36,7 +36,8 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("n_octaves", C.c_int32)] + \
-               [(n, C.POINTER(C.c_int32)) for n in ("raw_extrema", "candidates", "keypoints", "oriented", "descriptors")]
+               [(n, C.POINTER(C.c_int32)) for n in ("raw_extrema", "candidates", "keypoints", "oriented", "descriptors")] + \
+               [("raw_extrema_exact", C.c_int32)]
 
 
 extremum_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("scale", "<i4")])
@@ -94,6 +95,7 @@ def load():
     L.siftmi_get_sigma.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.siftmi_get_weights.argtypes = [vp, C.c_int, vp, i32p]
     L.siftmi_copy_gaussian.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+    L.siftmi_copy_dog.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     L.siftmi_copy_extrema.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, i32p]
     L.siftmi_copy_orientations.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, i32p]
     L.siftmi_copy_descriptor_floats.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int32, i32p]

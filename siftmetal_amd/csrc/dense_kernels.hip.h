@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace siftmi {
 
@@ -559,6 +560,290 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
         if (!body(st, pfA, pfB)) break;
         if (!step_ok(st + 1)) break;
         if (!body(st + 1, pfB, pfA)) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring form of the marching layer blur (round 2; replaces blur_march_kernel for the large launches).
+// Same strip walk, but the LDS window is a RING of NR = 2S rows addressed modulo NR, so nothing is carried:
+// blur_march_kernel copied the last 2R blurred rows to the top of its window through registers after every
+// step (26 rows per 16 new ones at R = 13: more LDS store traffic than the staging itself).  With the
+// LDS that frees, a step is S = 32 rows, and the vertical pass gives every wavefront ONE group of S/4 = 8
+// output rows with a lane owning 2 adjacent columns: the ring slot of every window row is then wave-uniform
+// (scalar address arithmetic, one v_add per read), the reads are ds_read_b64 at consecutive lanes (full LDS
+// rate at any row pitch), and a window row is read (8 + 2R)/8 times per output row instead of (2 + 2R)/2:
+// 17 B of LDS reads per pixel at R = 13 against 56 B.  The tap weights are symmetric (w[i] == w[2R - i]
+// bit for bit, see gaussian_weights) and held in R + 1 VGPRs.
+// Row bookkeeping: u = image row - ybeg - R.  Step st stages rows u in [st S, st S + S) into ring half
+// (st & 1); the chunk's prologue also stages u in [-2R, 0) (slots NR - 2R ... NR - 1).  Output row
+// y0 + j of step st reads u in [st S + j - 2R, st S + j].
+// Same arithmetic and tap order as blur2_kernel / blur_march_kernel: bit-identical results.
+template <int R, int S_ = 32>
+struct RingGeom {
+    // staged halo: 8 or 16 columns per side, so that a step's S new rows are a whole number of float4 (+ one float2)
+    // per lane -- every lane issues the same loads, none masked (see the note on s_waitcnt at the kernel)
+    static constexpr int RP = R <= 8 ? 8 : 16;
+    static constexpr int TW = 128, S = S_, NTHR = 256, NR = 2 * S_, RB = S_ / 4;
+    static constexpr int LW = TW + 2 * RP, NT = 2 * R + 1;
+    static constexpr int V = LW / 4;                                    // float4 per staged row
+    static constexpr int NPF4 = LW / 32;                                // 8 lanes per row: whole float4 per lane ...
+    static constexpr int REM = (LW - 32 * NPF4) / 8;                    // ... + this many floats per lane (0 or 2)
+    static_assert(S * 8 == NTHR && (REM == 0 || REM == 2) && (NPF4 * 4 + REM) * 8 == LW, "prefetch decomposition");
+    static_assert(R <= 15 && S + 2 * R <= NR, "window must fit the ring");
+    static_assert((NR & (NR - 1)) == 0, "ring size must be a power of two");
+    // max|Eh| per (ring row, cell) for the activity flags: in the first two halo columns of the row when no tap reads
+    // that float4 (R <= 4, 9 <= R <= 12), else behind the ring
+    static constexpr bool EHM_IN_ROW = RP - R >= 4;
+    static constexpr size_t lds_bytes = (size_t)LW * NR * sizeof(float);
+    static constexpr size_t lds_bytes_act = lds_bytes + (EHM_IN_ROW ? 0 : (size_t)NR * 2 * sizeof(float));
+};
+
+template <int R>
+struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-identical, the weights are symmetric)
+    float w[R + 1];
+    __device__ __forceinline__ explicit VTapsSym(const TapWeights &wt) {
+#pragma unroll
+        for (int i = 0; i <= R; i++) asm volatile("v_mov_b32 %0, %1" : "=v"(w[i]) : "s"(wt.w[i]));
+    }
+    __device__ __forceinline__ float operator()(int i) const { return w[i <= R ? i : 2 * R - i]; }
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) volatile f32x2 lds_cv_f32x2;
+
+// Register prefetch and s_waitcnt: the S new rows of step st+1 are requested at the start of step st and written to LDS
+// at its end.  hipcc counts outstanding vector-memory operations per basic block and merges conservatively at joins, so
+// every branch around a store (row / column guards) between the loads and their use made it wait for vmcnt(0) there --
+// draining the step's stores and serialising load latency with compute (round 1's "two-deep" prefetch was in fact
+// zero-deep; long chunks ran 2x slower than short, prologue-dominated ones).  Interior steps therefore run a FAST body
+// whose loads and stores are unconditional straight-line code: the compiler's own count is then exact (vmcnt(8): the
+// eight row stores stay in flight) and the loads have a whole step of FMA work to land.
+// DBG (tools/ubench only; 0 in the library): 1 = s_memtime stamps per phase, summed per wavefront into the buffer passed as
+// act.dst ([workgroup][wave][8] u64); 2 = no global stores, 4 = no global loads, 8 = no horizontal-pass arithmetic,
+// 16 = no vertical-pass arithmetic (timing ablations, wrong results).
+template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0>
+__global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                             size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
+                                                             int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act) {
+    using G = RingGeom<R, S_>;
+    constexpr int NR = G::NR, LW = G::LW, RP = G::RP, S = G::S, RB = G::RB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // max|Eh| of (ring row, cell): only with ACT (see RingGeom::EHM_IN_ROW)
+    auto ehm = [&](int slot, int cell) -> float & { return G::EHM_IN_ROW ? lds[slot * LW + cell] : lds[LW * NR + slot * 2 + cell]; };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware 1-D order (see blur2_kernel): frame, chunk, strip with the strip index fastest
+    const int tx = (w + G::TW - 1) / G::TW;
+    const int nch = (h + ch_rows - 1) / ch_rows;
+    const int total = tx * nch * n_frames;
+    const int per_xcd = (total + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= total) return;
+    const int frame = t / (tx * nch);
+    const int rem = t - frame * (tx * nch);
+    const int chunk = rem / tx, bx = rem - chunk * tx;
+    const int x0 = bx * G::TW, ybeg = chunk * ch_rows;
+    const int nst = (min(ch_rows, h - ybeg) + S - 1) / S;   // steps of this chunk
+    const float *__restrict__ in = src + (size_t)frame * src_frame_stride;
+    float *__restrict__ out = dst + (size_t)frame * dst_frame_stride;
+    // general staging of rows u in [u0, u1) (mirror resolved per element)
+    auto stage_rows = [&](int u0, int u1) {
+        for (int idx = tid; idx < (u1 - u0) * LW; idx += G::NTHR) {
+            const int lu = idx / LW, lx = idx - lu * LW;
+            const int slot = (u0 + lu + NR) & (NR - 1);
+            const int sx = symm(x0 - RP + lx, w), sy = symm(ybeg + R + u0 + lu, h);
+            lds[slot * LW + lx] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : in[(size_t)sy * w + sx];
+        }
+    };
+    // Row loads of the fast path.  8 lanes per row: lane q of a row takes the float4 columns q + 8 j (j < NPF4) and, when
+    // the row length leaves a remainder, the float2 at float 32 NPF4 + 2 q -- one address register per side and immediate
+    // offsets.  The mirror extension costs no branch: a row index is mirrored once per lane (symm), and a float4 that lies
+    // outside the image on the left / right is the float4 at -gx - 4 / 2w - 4 - gx with its elements reversed (w % 4 == 0,
+    // single reflection), so border strips and border rows issue exactly the loads interior ones do.
+    // Needs: w a multiple of 4, a whole strip, and an image large enough for single reflections.
+    const bool colfast = (w & 3) == 0 && w >= 64 && h >= 64 && x0 + G::TW <= w;
+    const int pf_row = tid >> 3, pf_q = tid & 7;
+    auto load_rows = [&](int y_first, int nrows, f32x4 (&buf)[G::NPF4], f32x2 &rem) {     // image rows y_first + (0 ... nrows-1)
+        const int sy = symm(y_first + min(pf_row, nrows - 1), h);
+        const float *rowp = in + (size_t)sy * w;
+#pragma unroll
+        for (int j = 0; j < G::NPF4; j++) {
+            const int gx = x0 - RP + 4 * pf_q + 32 * j;
+            const bool mir = gx < 0 || gx >= w;
+            const int g2 = gx < 0 ? -gx - 4 : (gx >= w ? 2 * w - 4 - gx : gx);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + g2);
+            buf[j].x = mir ? v.w : v.x; buf[j].y = mir ? v.z : v.y; buf[j].z = mir ? v.y : v.z; buf[j].w = mir ? v.x : v.w;
+        }
+        if (G::REM) {                                        // the last 16 halo columns, right of the strip
+            const int gx = x0 - RP + 32 * G::NPF4 + 2 * pf_q;
+            const bool mir = gx >= w;
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(rowp + (mir ? 2 * w - 2 - gx : gx));
+            rem.x = mir ? v.y : v.x; rem.y = mir ? v.x : v.y;
+        }
+    };
+    auto store_rows = [&](int u_first, int nrows, const f32x4 (&buf)[G::NPF4], const f32x2 &rem) {   // -> ring rows u_first + ...
+        float *rowp = lds + ((u_first + min(pf_row, nrows - 1) + NR) & (NR - 1)) * LW;     // lanes past nrows repeat the last row
+#pragma unroll
+        for (int j = 0; j < G::NPF4; j++) *reinterpret_cast<f32x4 *>(rowp + 4 * pf_q + 32 * j) = buf[j];
+        if (G::REM) *reinterpret_cast<f32x2 *>(rowp + 32 * G::NPF4 + 2 * pf_q) = rem;
+    };
+
+    // prologue: rows u in [-2R, S) of the first step.  Fast path: every load of both batches in flight before the first
+    // LDS write (a load -> wait -> write loop cost nine memory latencies per chunk, as long as five steps).
+    if (colfast) {
+        f32x4 a[G::NPF4], b[G::NPF4];
+        f32x2 ar, br;
+        load_rows(ybeg - R, S, a, ar);
+        load_rows(ybeg - R + S, 2 * R, b, br);
+        store_rows(-2 * R, S, a, ar);
+        store_rows(-2 * R + S, 2 * R, b, br);
+    } else {
+        stage_rows(-2 * R, S);
+    }
+    const VTapsSym<R> tw(wt);
+
+    unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+    auto stamp = [&](int k) {                                // DBG & 1: time since the previous stamp -> dsum[k]
+        if (!(DBG & 1)) return;
+        unsigned long long tnow;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (k >= 0) dsum[k] += tnow - dlast;
+        dlast = tnow;
+    };
+    stamp(-1);
+    auto body = [&](auto fast_tag, int st) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const int y0 = ybeg + st * S;                        // first output row of this step
+        const bool has_next = FAST || st + 1 < nst;
+        lds_barrier();                                       // B1: this step's rows are in LDS
+        stamp(7);
+        f32x4 pf[G::NPF4];
+        f32x2 pfr;
+        if (FAST && (DBG & 4)) {
+#pragma unroll
+            for (int j = 0; j < G::NPF4; j++) pf[j] = f32x4{1.0f, 2.0f, 3.0f, (float)j};
+            pfr = f32x2{1.0f, 2.0f};
+        } else
+        if (FAST) load_rows(ybeg + R + (st + 1) * S, S, pf, pfr);   // the next step's S new rows -> registers, all lanes alike
+
+        stamp(0);
+        // horizontal pass, in place (first step: the S + 2R prologue rows; later steps: the S new rows)
+        const int hb = st == 0 ? -2 * R : st * S, hn = st == 0 ? S + 2 * R : S;
+#pragma unroll 1
+        for (int item = tid; item < ((DBG & 8) ? 0 : hn * 32); item += G::NTHR) {
+            const int slot = (hb + (item >> 5) + NR) & (NR - 1), c4 = (item & 31) * 4;
+            float *rowp = lds + slot * LW;
+            constexpr int M0 = (RP - R) / 4, M1 = (RP + R + 3) / 4 + 1;    // float4 of the row segment that hold the taps' operands
+            float v[4 * (M1 - M0)];
+            const lds_cv_f32x4 *rp4 = (const lds_cv_f32x4 *)(rowp + c4);
+#pragma unroll
+            for (int m = M0; m < M1; m++) {
+                const f32x4 tv = rp4[m];
+                v[4 * (m - M0) + 0] = tv.x; v[4 * (m - M0) + 1] = tv.y; v[4 * (m - M0) + 2] = tv.z; v[4 * (m - M0) + 3] = tv.w;
+            }
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < G::NT; i++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k] = fmaf(tw(i), v[(RP - R - 4 * M0) + k + i], acc[k]);
+            }
+            *reinterpret_cast<float4 *>(rowp + RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (ACT) {                                      // max |hb - raw| over this row's 64-column cell (16 lanes x 4 columns)
+                constexpr int C = RP - 4 * M0;
+                float e = fmaxf(fmaxf(fabsf(acc[0] - v[C + 0]), fabsf(acc[1] - v[C + 1])),
+                                fmaxf(fabsf(acc[2] - v[C + 2]), fabsf(acc[3] - v[C + 3])));
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) e = fmaxf(e, __shfl_xor(e, off, 16));
+                if ((tid & 15) == 0) ehm(slot, (tid >> 4) & 1) = e;
+            }
+        }
+        stamp(1);
+        lds_barrier();                                       // B2: blurred rows complete
+        stamp(2);
+
+        // vertical pass: wavefront wv owns output rows wv RB ... wv RB + RB - 1 of the step, a lane 2 columns
+        {
+            const int u0 = st * S + wv * RB - 2 * R;         // first window row (wave-uniform)
+            const float *colp = lds + RP + 2 * lane;
+            f32x2 cen[ACT ? RB : 1];                        // hb under each output (the centre tap's operand), for the activity bound
+            f32x2 acc[RB];
+#pragma unroll
+            for (int rr = 0; rr < RB; rr++) { acc[rr].x = 0.0f; acc[rr].y = 0.0f; }
+#pragma unroll
+            for (int k = 0; k < ((DBG & 16) ? 0 : RB + 2 * R); k++) {
+                const int slot = (u0 + k + NR) & (NR - 1);
+                const f32x2 v = *(const lds_cv_f32x2 *)(colp + slot * LW);
+#pragma unroll
+                for (int rr = 0; rr < RB; rr++) {
+                    const int i = k - rr;
+                    if (ACT && i == R) cen[rr] = v;
+                    if (i >= 0 && i < G::NT) {
+                        acc[rr].x = fmaf(tw(i), v.x, acc[rr].x);
+                        acc[rr].y = fmaf(tw(i), v.y, acc[rr].y);
+                    }
+                }
+            }
+            // pin the accumulators: otherwise LLVM sinks each row's FMA chain into the store guards below
+#pragma unroll
+            for (int rr = 0; rr < RB; rr++) asm volatile("" : "+v"(acc[rr].x), "+v"(acc[rr].y));
+            stamp(3);
+            const int gx = x0 + 2 * lane;
+#pragma unroll
+            for (int rr = 0; rr < ((DBG & 2) ? 0 : RB); rr++) {
+                const int gy = y0 + wv * RB + rr;            // wave-uniform
+                if (!FAST && gy >= h) continue;
+                float *o = out + (size_t)gy * w + gx;
+                if (FAST || (gx + 1 < w && (w & 1) == 0)) {
+                    *reinterpret_cast<f32x2 *>(o) = acc[rr];
+                } else {
+                    if (gx + 0 < w) o[0] = acc[rr].x;
+                    if (gx + 1 < w) o[1] = acc[rr].y;
+                }
+                if (DEC && ((wv * RB + rr) & 1) == 0 && (FAST || (((gy & 1) == 0) && (gy >> 1) < dec.h2))) {   // y0 is even on the FAST path; gx is even
+                    if (FAST || ((gx >> 1) < dec.w2 && gx < w))
+                        dec.dst[(size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1)] = acc[rr].x;
+                }
+                if (ACT) {                                  // 32 lanes = 64 columns = one cell of this row
+                    const int half = lane >> 5;
+                    const int slot_c = (st * S + wv * RB + rr - R + NR) & (NR - 1);           // ring row under this output row
+                    const float eh = ehm(slot_c, half);
+                    const float lim = act.thr * 0.9999f;
+                    const bool f = (gx + 0 < w && fabsf(acc[rr].x - cen[rr].x) + eh > lim) || (gx + 1 < w && fabsf(acc[rr].y - cen[rr].y) + eh > lim);
+                    const unsigned long long b = __ballot(f);
+                    const int cell = (x0 >> 6) + half;
+                    if ((lane & 31) == 0 && cell < act.ncell)
+                        act.dst[(size_t)frame * act.frame_stride + (size_t)gy * act.ncell + cell] = ((b >> (lane & 32)) & 0xffffffffull) ? 1 : 0;
+                }
+            }
+        }
+        stamp(4);
+        if (!has_next) return;                               // uniform
+        lds_barrier();                                       // B3: every read of the other ring half is done
+        stamp(5);
+        if (FAST) store_rows((st + 1) * S, S, pf, pfr);
+        else stage_rows((st + 1) * S, (st + 2) * S);        // general step: mirror per element, straight to LDS
+        // keeps LLVM from tail-merging the LDS writes above of the two instantiations: merged, they would be reached from
+        // the general body as well and get its conservative s_waitcnt vmcnt(0)
+        if (FAST) asm volatile("; end of a FAST ring step" ::: "memory");
+        else asm volatile("; end of a general ring step" ::: "memory");
+        if (DBG & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(6);
+    };
+    // FAST steps: a column-fast strip, a next step to prefetch for, all S output rows inside the image (and, with DEC, an
+    // even first row and a decimated row for every even output row)
+    const bool strip_fast = colfast && (!DEC || ((ybeg & 1) == 0 && (S & 1) == 0));
+    for (int st = 0; st < nst; st++) {
+        const int y0 = ybeg + st * S;
+        const bool fast = strip_fast && st + 1 < nst && y0 + S <= h && (!DEC || ((y0 + S - 1) >> 1) < dec.h2);
+        if (fast) body(std::true_type{}, st);
+        else body(std::false_type{}, st);
+    }
+    if ((DBG & 1) && lane == 0) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(act.dst) + ((size_t)t * 4 + wv) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = dsum[k];
     }
 }
 

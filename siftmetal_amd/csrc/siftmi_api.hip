@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,29 @@ static int set_error(int code, const char *fmt, ...) {
         if (e_ != hipSuccess)                                                                           \
             return set_error(SIFTMI_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// Stage markers for rocprofv3 --marker-trace (replaces the os_signpost intervals of Utilities/Performance.swift:12-20 at its
+// call sites SIFT.swift:155,179,192,212,226).  librocprofiler-sdk-roctx is looked up at run time so that the library has
+// no link-time dependency on the profiler; without it the ranges are no-ops.
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        if (getenv("SIFTMI_NO_ROCTX")) return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+static const RoctxApi &roctx() { static RoctxApi api; return api; }
+struct StageRange {                            // host-side range around the launches of one stage
+    bool on;
+    explicit StageRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~StageRange() { if (on) roctx().pop(); }
+};
 
 struct EventPair { hipEvent_t a, b; int stage; };
 
@@ -121,6 +145,14 @@ struct siftmi_ctx {
     int last_frames = 0;                      // frames of the last batch call
     int last_sub_frames = 0;                  // frames resident in the pyramid
     bool pyramid_valid = false;
+    // Ordering between calls: the context's scratch (pyramid, lists, counters) is shared by every entry point, and the
+    // device-resident batch call runs on a caller-supplied stream.  Every entry point records ev_last on the stream it
+    // used when it has enqueued its work; the next one makes its stream wait for it (a no-op on the same stream) and the
+    // host-reading introspection calls synchronise on it.
+    hipEvent_t ev_last = nullptr;
+    bool last_recorded = false;
+    bool stats_on_device = false;             // the last call was device-resident: h_stats is refreshed lazily by siftmi_get_stats
+    bool raw_exact = true;                    // raw_extrema of the last call counts every row (no activity-flag skipping)
     PyramidDesc P;
     DetectParams prm;
     // hipGraph cache of the batched device path (one call signature)
@@ -136,6 +168,7 @@ struct siftmi_ctx {
     // with direct launches.  Executable graphs are never destroyed (runtime defect, see drop_graphs()).
     struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
     std::vector<GraphEntry> gcache;
+    std::vector<GraphKey> gseen;               // signatures seen once (not yet captured), oldest first
     static constexpr size_t GCACHE_MAX = 64;
     bool graph_failed = false;
     // fork/join of the octave chains inside a captured graph (small launches only, see run_dense_detect)
@@ -166,6 +199,8 @@ static int gaussian_weights(float s, TapWeights &out) {
     }
     for (int i = 0; i < size; i++) out.w[i] = out.w[i] / t;
     for (int i = size; i < 32; i++) out.w[i] = 0.0f;
+    // k enters only as k * k, so w[i] == w[size - 1 - i] bit for bit; blur_ring_kernel keeps radius + 1 of them (VTapsSym)
+    for (int i = 0; i < size; i++) if (memcmp(&out.w[i], &out.w[size - 1 - i], sizeof(float)) != 0) return -1;
     return size;
 }
 
@@ -223,6 +258,7 @@ static void free_ctx(siftmi_ctx *c) {
         if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
         if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
     }
+    if (c->ev_last) (void)hipEventDestroy(c->ev_last);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -299,6 +335,11 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
         c->P.kp_off[o] = kp_off; kp_off += c->P.cap_kp[o];
         c->P.desc_off[o] = desc_off; desc_off += c->P.cap_desc[o];
     }
+    // the keypoint sort packs (scale * h + y) * w + x of octave 0 into 32 bits (refine_kernel / kp_row_* kernels)
+    if ((long long)(nspo + 2) * c->ow[0] * c->oh[0] >= (1ll << 31)) {
+        free_ctx(c);
+        return set_error(SIFTMI_E_BADARG, "input %dx%d too large: (nspo + 2) x octave-0 pixels must stay below 2^31", W, H);
+    }
     c->frame_stride = off;
     c->P.frame_stride = off; c->P.n_octaves = c->n_oct; c->P.nspo = nspo;
     c->P.ext_frame = ext_off; c->P.kp_frame = kp_off; c->P.desc_frame = desc_off;
@@ -316,6 +357,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     hipError_t e = hipSetDevice(hip_device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
     for (int i = 0; i < 2; i++) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming);
@@ -365,6 +407,24 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
 }
 
 // ------------------------------------------------------------------------------------------------
+// ordering of a call on stream `st` after the previous call on this context (see siftmi_ctx::ev_last)
+static int order_begin(siftmi_ctx *c, hipStream_t st) {
+    if (c->last_recorded) HIP_TRY(hipStreamWaitEvent(st, c->ev_last, 0));
+    return SIFTMI_OK;
+}
+static int order_end(siftmi_ctx *c, hipStream_t st) {
+    HIP_TRY(hipEventRecord(c->ev_last, st));
+    c->last_recorded = true;
+    return SIFTMI_OK;
+}
+// host-side reads of the context's device state: everything enqueued by the last call has finished
+static int order_sync(siftmi_ctx *c) {
+    if (c->last_recorded) HIP_TRY(hipEventSynchronize(c->ev_last));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SIFTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // timing helpers
 static void t_begin(siftmi_ctx *c, int stage) {
     if (!c->timing) return;
@@ -393,18 +453,17 @@ static void t_collect(siftmi_ctx *c) {
 
 // ------------------------------------------------------------------------------------------------
 // launches
-// Steps of 16 rows per marching-blur chunk.  8 (128 rows) for tall images: enough workgroups for many rounds.  Octaves of
-// up to 1200 rows get 4 chunks per strip instead (1080 rows: 17 steps): with ~4000 workgroups the launch was only 4-5
-// rounds of resident workgroups, the last one mostly empty; fewer, longer ones also re-blur fewer halo rows (-2 % blur time).
-static int march_spc(int h) {
-    return h <= 1200 ? std::max(8, (h + 63) / 64) : 8;
-}
+// Rows per chunk of the marching (ring) blur: a workgroup walks its 128-column strip down one chunk in steps of 32 rows.
+// Short chunks win although each one re-blurs 2R halo rows in its prologue (tools/ubench/blur_variants.hip, 32 x 3840x2160:
+// 128-256 rows per chunk fastest at every radius, whole-height strips 2x slower): many more workgroups than resident
+// slots keeps workgroups out of phase with each other, so one's loads overlap another's arithmetic.
+static int march_chunk_rows(int /*h*/) { return 128; }
 
 // the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 2000)
 static bool uses_march(const siftmi_ctx *c, int w, int h, int nf) {
-    using Gm = MarchGeom<1, 16>;
-    const int spc = march_spc(h);
-    const long long total = (long long)((w + Gm::TW - 1) / Gm::TW) * ((h + spc * Gm::S - 1) / (spc * Gm::S)) * nf;
+    using Gm = RingGeom<1>;
+    const int chr = march_chunk_rows(h);
+    const long long total = (long long)((w + Gm::TW - 1) / Gm::TW) * ((h + chr - 1) / chr) * nf;
     return total >= c->march_min_blocks;
 }
 
@@ -413,22 +472,20 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
                                  const TapWeights &wt, const SeedSource &seed, const Decimate &dec, const Activity &act) {
     bool march = false;
     if constexpr (!SEED) {
-        // large launches: marching form (no vertical-halo recompute, next rows prefetched under the FMA phases);
-        // 12-29 % faster than the tile form at every radius on 32 x 3840x2160 (tools/ubench/blur_variants.hip),
-        // but it needs enough strips x chunks to fill the chip, so small octaves keep the tile kernel.
-        constexpr int S = 16;
-        using Gm = MarchGeom<R, S>;
-        const int spc = march_spc(h);
-        const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + spc * Gm::S - 1) / (spc * Gm::S)) * nf;
+        // large launches: marching form (no vertical-halo recompute beyond a chunk's prologue, next rows prefetched under
+        // the FMA phases); it needs enough strips x chunks to fill the chip, so small octaves keep the tile kernel.
+        using Gm = RingGeom<R>;
+        const int chr = march_chunk_rows(h);
+        const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + chr - 1) / chr) * nf;
         if (uses_march(c, w, h, nf)) {
             march = true;
             dim3 grid(((total + 7) / 8) * 8, 1, 1);
             if (act.dst)
-                hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC, false, 256, 0, 128, 4, true>), grid, dim3(Gm::NTHR), Gm::lds_bytes_act, st, src, dst, w, h,
-                                   c->frame_stride, c->frame_stride, wt, nf, spc, dec, act);
+                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, true>), grid, dim3(Gm::NTHR), Gm::lds_bytes_act, st, src, dst, w, h,
+                                   c->frame_stride, c->frame_stride, wt, nf, chr, dec, act);
             else
-                hipLaunchKernelGGL((blur_march_kernel<R, 4, S, DEC>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
-                                   c->frame_stride, wt, nf, spc, dec, act);
+                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, false>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
+                                   c->frame_stride, wt, nf, chr, dec, act);
         }
     }
     if (!march) {
@@ -521,6 +578,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
                             bool fork, bool first_of_call) {
     const int NG = c->nspo + 3;
     int rc;
+    StageRange rg("siftmi pyramid + extrema (DifferenceOfGaussians.encode, findKeypoints)");
     if (fork && (rc = ensure_fork(c))) return rc;
     SeedSource seed;
     seed.pixels = (const unsigned char *)d_pixels; seed.frame_stride = frame_stride; seed.row_stride = row_stride;
@@ -541,6 +599,8 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
         hipStream_t next = cur;
         // DoG activity flags for the extrema scan: only when every layer of this octave goes through the marching blur
         c->act_valid[o] = !c->cfg.count_raw_extrema && c->ow[o] >= 3 && c->oh[o] >= 3 && uses_march(c, c->ow[o], c->oh[o], nf);
+        if (o == 0 && first_of_call) c->raw_exact = true;
+        if (c->act_valid[o]) c->raw_exact = false;
         for (int s = 1; s < NG; s++) {
             Decimate dec = nodec;
             if (s == c->nspo && o + 1 < c->n_oct) {
@@ -573,6 +633,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
 // refine -> sort  (SIFT.swift:190-202)
 static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
     const int groups = nf * c->n_oct;
+    StageRange rg("siftmi refine + sort (interpolateKeypoints)");
     t_begin(c, SIFTMI_T_REFINE);
     hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
     hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
@@ -593,6 +654,7 @@ static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
 // orientation -> expansion -> descriptors  (SIFT.swift:207-238)
 static int run_describe(siftmi_ctx *c, hipStream_t st, int nf) {
     const int groups = nf * c->n_oct;
+    StageRange rg("siftmi orientation + descriptors (getDescriptors)");
     t_begin(c, SIFTMI_T_ORIENT);
     hipLaunchKernelGGL(orientation_kernel, dim3(256, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                        c->d_ori_angles);
@@ -617,6 +679,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf) {
 static int run_pack(siftmi_ctx *c, hipStream_t st, int nf, int frame_base, int total_frames, KeypointRec *kp_out, long long kp_cap,
                     DescriptorRec *desc_out, long long desc_cap, int32_t *d_counts, int32_t *d_stats) {
     const int groups = nf * c->n_oct;
+    StageRange rg("siftmi pack results");
     t_begin(c, SIFTMI_T_PACK);
     hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(64), 0, st, c->P, nf, frame_base, total_frames, cnt(c, C_RAW), cnt(c, C_CAND),
                        cnt(c, C_KP), cnt(c, C_ORIENTED), cnt(c, C_DESC), c->d_dst_off, c->d_dst_off + (size_t)c->B * c->n_oct, d_counts,
@@ -640,6 +703,7 @@ static void drop_graphs(siftmi_ctx *c) {
     if (c->gcache.empty()) return;
     (void)hipDeviceSynchronize();
     c->gcache.clear();
+    c->gseen.clear();
 }
 
 static int ensure_stats(siftmi_ctx *c, int n_frames) {
@@ -679,7 +743,7 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
         if ((rc = run_pack(c, st, nf, f0, n_frames, d_kp, kp_cap, d_desc, desc_cap, d_counts, c->d_stats))) return rc;
         c->last_sub_frames = nf;
     }
-    if (d_totals) HIP_TRY(hipMemcpyAsync(d_totals, c->d_state, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (d_totals) HIP_TRY(hipMemcpyAsync(d_totals, c->d_state, sizeof(PackState), hipMemcpyDeviceToDevice, st));   // {n_kp, n_desc, overflow flags, 0}
     return SIFTMI_OK;
 }
 
@@ -695,11 +759,21 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     rc = ensure_stats(c, n_frames);
     if (rc) return rc;
+    if ((rc = order_begin(c, st))) return rc;            // after whatever the previous call left running on another stream
+    c->stats_on_device = true;
     const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && getenv("SIFTMI_NO_GRAPH") == nullptr;
     if (want_graph) {
         const siftmi_ctx::GraphKey key{d_pixels, n_frames, format, row_stride, frame_stride, d_keypoints, (long long)kp_capacity, d_descriptors,
                                        (long long)desc_capacity, d_counts, d_totals, st};
         hipGraphExec_t exec = nullptr;
+        // a signature is captured on its SECOND sighting: a caller that passes fresh buffers with every call would
+        // otherwise pay capture + instantiation each time and fill the cache with graphs that are never replayed
+        bool seen = false;
+        for (const auto &k : c->gseen) seen = seen || k == key;
+        if (!seen) {
+            if (c->gseen.size() >= 16) c->gseen.erase(c->gseen.begin());
+            c->gseen.push_back(key);
+        }
         for (size_t i = 0; i < c->gcache.size(); i++)
             if (c->gcache[i].key == key) {                       // hit: move to the back (most recently used)
                 const siftmi_ctx::GraphEntry hit = c->gcache[i];
@@ -708,7 +782,7 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
                 exec = hit.exec;
                 break;
             }
-        if (!exec && c->gcache.size() < siftmi_ctx::GCACHE_MAX) {
+        if (!exec && seen && c->gcache.size() < siftmi_ctx::GCACHE_MAX) {
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
@@ -730,11 +804,12 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
             }
         }
         if (exec) {
+            StageRange rg("siftmi graph replay (detect+describe batch)");
             HIP_TRY(hipGraphLaunch(exec, st));
             c->last_sub_frames = std::min(c->B, n_frames - ((n_frames - 1) / c->B) * c->B);
             c->last_frames = n_frames;
             c->pyramid_valid = true;
-            return SIFTMI_OK;
+            return order_end(c, st);
         }
     }
     rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
@@ -742,7 +817,7 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
     if (rc) return rc;
     c->last_frames = n_frames;
     c->pyramid_valid = true;
-    return SIFTMI_OK;
+    return order_end(c, st);
 }
 
 static int grow_outputs(siftmi_ctx *c, long long kp_need, long long desc_need) {
@@ -841,6 +916,8 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     if ((rc = ensure_stats(c, n_frames))) return rc;
     hipStream_t st = c->stream;
     c->tstream = st;
+    if ((rc = order_begin(c, st))) return rc;
+    c->stats_on_device = false;
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const void *d_px; size_t d_row, d_frame;
@@ -868,6 +945,7 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     t_collect(c);
     c->last_frames = n_frames;
     c->pyramid_valid = true;
+    if ((rc = order_end(c, st))) return rc;
     if (keypoints) *keypoints = c->h_kp.data();
     if (kp_counts) *kp_counts = c->h_counts.data();
     if (descriptors) *descriptors = c->h_desc.data();
@@ -885,6 +963,8 @@ extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->tstream = st;
+    if ((rc = order_begin(c, st))) return rc;
+    c->stats_on_device = false;
     const void *d_px; size_t d_row, d_frame;
     if ((rc = stage_input(c, 1, pixels, format, row_stride, 0, on_device, &d_px, &d_row, &d_frame))) return rc;
     if ((rc = run_dense_detect(c, st, 1, d_px, format, d_row, d_frame, false, true))) return rc;
@@ -914,6 +994,7 @@ extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size
     HIP_TRY(hipStreamSynchronize(st));
     t_collect(c);
     c->last_frames = 1; c->last_sub_frames = 1; c->pyramid_valid = true;
+    if ((rc = order_end(c, st))) return rc;
     if (keypoints) *keypoints = c->h_kp.data();
     if (flags) return overflow_error(c, flags);
     return SIFTMI_OK;
@@ -927,6 +1008,11 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->tstream = st;
+    {
+        const int rc0 = order_begin(c, st);
+        if (rc0) return rc0;
+    }
+    if (c->stats_on_device) { c->h_stats.clear(); c->stats_on_device = false; }
     const size_t cs = (size_t)c->B * c->n_oct;
     std::vector<int32_t> h(cs, 0);
     size_t pos = 0;
@@ -971,6 +1057,7 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
     HIP_TRY(hipStreamSynchronize(st));
     t_collect(c);
     c->last_frames = 1;
+    if ((rc = order_end(c, st))) return rc;
     if (descriptors) *descriptors = c->h_desc.data();
     if (flags) return overflow_error(c, flags);
     return SIFTMI_OK;
@@ -989,6 +1076,10 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
     if (n_source == 0 || n_target == 0) return SIFTMI_OK;                    // no target: every match is nil (:340-346)
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    {
+        const int rc0 = order_begin(c, st);
+        if (rc0) return rc0;
+    }
     auto grow = [&](void **p, long long *cap, long long need, size_t elem) -> int {
         if (need <= *cap) return SIFTMI_OK;
         if (*p) (void)hipFree(*p);
@@ -1064,6 +1155,10 @@ extern "C" int siftmi_approximate_match(siftmi_ctx *c, const siftmi_descriptor *
     if (n_source == 0 || n_target == 0) return SIFTMI_OK;                    // empty trie: no queue entries, every match is nil
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    {
+        const int rc0 = order_begin(c, st);
+        if (rc0) return rc0;
+    }
     auto grow = [&](void **p, long long *cap, long long need, size_t elem) -> int {
         if (need <= *cap) return SIFTMI_OK;
         if (*p) (void)hipFree(*p);
@@ -1146,7 +1241,16 @@ extern "C" void siftmi_descriptor_to_reference(const siftmi_descriptor *in, int6
 extern "C" int siftmi_get_stats(siftmi_ctx *c, siftmi_stats *out) {
     if (!c || !out) return set_error(SIFTMI_E_BADARG, "null argument");
     const size_t ng = (size_t)c->last_frames * c->n_oct;
+    if (c->stats_on_device && ng > 0) {                    // last call was device-resident: fetch its statistics block now
+        HIP_TRY(hipSetDevice(c->device));
+        const int rc0 = order_sync(c);
+        if (rc0) return rc0;
+        c->h_stats.resize(5 * ng);
+        HIP_TRY(hipMemcpy(c->h_stats.data(), c->d_stats, 5 * ng * sizeof(int32_t), hipMemcpyDeviceToHost));
+        c->stats_on_device = false;
+    }
     if (c->h_stats.size() < 5 * ng || ng == 0) return set_error(SIFTMI_E_STATE, "no statistics yet");
+    out->raw_extrema_exact = c->raw_exact ? 1 : 0;
     out->n_frames = c->last_frames; out->n_octaves = c->n_oct;
     out->raw_extrema = c->h_stats.data(); out->candidates = c->h_stats.data() + ng; out->keypoints = c->h_stats.data() + 2 * ng;
     out->oriented = c->h_stats.data() + 3 * ng; out->descriptors = c->h_stats.data() + 4 * ng;
@@ -1181,13 +1285,31 @@ extern "C" int siftmi_copy_gaussian(siftmi_ctx *c, int frame, int o, int s, floa
         return set_error(SIFTMI_E_BADARG, "bad frame/octave/layer");
     if (!c->pyramid_valid) return set_error(SIFTMI_E_STATE, "no pyramid resident");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rc0 = order_sync(c);
+        if (rc0) return rc0;
+    }
     HIP_TRY(hipMemcpy(dst, gauss_ptr(c, o, s) + (size_t)frame * c->frame_stride, (size_t)c->ow[o] * c->oh[o] * sizeof(float), hipMemcpyDeviceToHost));
     return SIFTMI_OK;
 }
 
+// DoG layer s = G[s + 1] - G[s] (Subtract.metal:12-21): the pipeline never materialises it (extrema / refinement form the
+// same single f32 subtraction on the fly), so this read-back subtracts the two Gaussian layers on the host.
+extern "C" int siftmi_copy_dog(siftmi_ctx *c, int frame, int o, int s, float *dst) {
+    if (!c || !dst || o < 0 || o >= c->n_oct || s < 0 || s >= c->nspo + 2 || frame < 0 || frame >= c->B)
+        return set_error(SIFTMI_E_BADARG, "bad frame/octave/scale");
+    const size_t n = (size_t)c->ow[o] * c->oh[o];
+    std::vector<float> lo(n);
+    int rc = siftmi_copy_gaussian(c, frame, o, s, lo.data());
+    if (rc) return rc;
+    if ((rc = siftmi_copy_gaussian(c, frame, o, s + 1, dst))) return rc;
+    for (size_t i = 0; i < n; i++) dst[i] = dst[i] - lo[i];
+    return SIFTMI_OK;
+}
+
 static int read_counter(siftmi_ctx *c, int which, int frame, int o, int32_t *v) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int rc0 = order_sync(c);
+    if (rc0) return rc0;
     HIP_TRY(hipMemcpy(v, cnt(c, which) + (size_t)frame * c->n_oct + o, sizeof(int32_t), hipMemcpyDeviceToHost));
     return SIFTMI_OK;
 }
@@ -1281,6 +1403,10 @@ extern "C" int siftmi_time_blur(siftmi_ctx *c, int o, int layer, int iters, doub
     SeedSource none; memset(&none, 0, sizeof(none));
     Decimate nodec; memset(&nodec, 0, sizeof(nodec));
     hipEvent_t a, b;
+    {
+        const int rc0 = order_begin(c, c->stream);
+        if (rc0) return rc0;
+    }
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, c->stream));
     for (int i = 0; i < iters; i++)
@@ -1297,7 +1423,10 @@ extern "C" int siftmi_time_blur(siftmi_ctx *c, int o, int layer, int iters, doub
 extern "C" int siftmi_synchronize(siftmi_ctx *c) {
     if (!c) return set_error(SIFTMI_E_BADARG, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rc0 = order_sync(c);
+        if (rc0) return rc0;
+    }
     t_collect(c);
     return SIFTMI_OK;
 }

@@ -5,18 +5,46 @@ scratch), so a stream of frames shards with no data-path collective; after a bat
 publishes its packed keypoint / descriptor buffers with ONE count exchange + padded all-gathers
 (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 The functions here are device-agnostic tensor plumbing; no SIFT arithmetic.
+
+Two forms:
+  gather_results   one-shot, sizes the payload gathers from the count exchange (one host sync).
+  ResultExchange   for a frame stream: the payload gathers of step k are sized from the counts of
+                   step k-1 (plus headroom), and the counts of step k are read on the host while step
+                   k+1 runs -- no host synchronisation between a step's kernels and its collectives.
+                   A step whose counts turn out to exceed what was sent is reported one step late
+                   (`incomplete_steps`) and the caller re-gathers it with gather_results.
 """
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
 
 KP_BYTES, DESC_BYTES = 44, 136
+TOTALS = 4                      # {n_keypoints, n_descriptors, overflow_flags, 0} (include/siftmi.h, d_totals)
 
 
 def shard_frames(n_frames: int, world_size: int, rank: int) -> List[int]:
     """frame i -> rank i mod world_size; returns this rank's frame indices."""
     return list(range(rank, n_frames, world_size))
+
+
+def _totals_row(totals: torch.Tensor) -> torch.Tensor:
+    """[1, TOTALS] int32 from a 2- or 4-element totals tensor."""
+    t = totals.reshape(-1)
+    if t.numel() < TOTALS:
+        t = torch.cat([t, torch.zeros(TOTALS - t.numel(), dtype=t.dtype, device=t.device)])
+    return t[:TOTALS].reshape(1, TOTALS).contiguous()
+
+
+def _payload_gathers(kp_bytes, desc_bytes, counts, n_kp, n_desc, group):
+    world = dist.get_world_size(group)
+    all_counts = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(all_counts, counts.contiguous().unsqueeze(0), group=group)
+    all_kp = torch.empty((world, n_kp * KP_BYTES), dtype=torch.uint8, device=kp_bytes.device)
+    dist.all_gather_into_tensor(all_kp, kp_bytes[:n_kp * KP_BYTES].unsqueeze(0), group=group)
+    all_desc = torch.empty((world, n_desc * DESC_BYTES), dtype=torch.uint8, device=desc_bytes.device)
+    dist.all_gather_into_tensor(all_desc, desc_bytes[:n_desc * DESC_BYTES].unsqueeze(0), group=group)
+    return all_counts, all_kp, all_desc
 
 
 def gather_results(kp_bytes: torch.Tensor, desc_bytes: torch.Tensor, counts: torch.Tensor, totals: torch.Tensor,
@@ -26,22 +54,81 @@ def gather_results(kp_bytes: torch.Tensor, desc_bytes: torch.Tensor, counts: tor
     kp_bytes   uint8 [kp_capacity * 44]    packed siftmi_keypoint records (first totals[0] valid)
     desc_bytes uint8 [desc_capacity * 136] packed siftmi_descriptor records (first totals[1] valid)
     counts     int32 [2, n_frames, n_octaves]
-    totals     int32 [2] = {n_keypoints, n_descriptors}
-    Returns per-rank views: {"totals": [world,2] (host), "counts": [world,2,F,O], "keypoints": [world, max_kp*44],
+    totals     int32 [2] or [4] = {n_keypoints, n_descriptors(, overflow_flags, 0)}
+    Returns per-rank views: {"totals": [world,4] (host), "counts": [world,2,F,O], "keypoints": [world, max_kp*44],
     "descriptors": [world, max_desc*136]} -- rank r's valid bytes are the first totals[r]*record_size of row r.
     """
     world = dist.get_world_size(group)
-    all_totals = torch.empty((world, 2), dtype=torch.int32, device=totals.device)
-    dist.all_gather_into_tensor(all_totals, totals.reshape(1, 2).contiguous(), group=group)
+    all_totals = torch.empty((world, TOTALS), dtype=torch.int32, device=totals.device)
+    dist.all_gather_into_tensor(all_totals, _totals_row(totals), group=group)
     host_totals = all_totals.cpu()                       # the one host sync of the exchange
     max_kp = max(int(host_totals[:, 0].max()), 1)
     max_desc = max(int(host_totals[:, 1].max()), 1)
     if max_kp * KP_BYTES > kp_bytes.numel() or max_desc * DESC_BYTES > desc_bytes.numel():
         raise RuntimeError("gather_results: a peer holds more records than this rank's buffer capacity")
-    all_counts = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(all_counts, counts.contiguous().unsqueeze(0), group=group)
-    all_kp = torch.empty((world, max_kp * KP_BYTES), dtype=torch.uint8, device=kp_bytes.device)
-    dist.all_gather_into_tensor(all_kp, kp_bytes[:max_kp * KP_BYTES].unsqueeze(0), group=group)
-    all_desc = torch.empty((world, max_desc * DESC_BYTES), dtype=torch.uint8, device=desc_bytes.device)
-    dist.all_gather_into_tensor(all_desc, desc_bytes[:max_desc * DESC_BYTES].unsqueeze(0), group=group)
+    all_counts, all_kp, all_desc = _payload_gathers(kp_bytes, desc_bytes, counts, max_kp, max_desc, group)
     return {"totals": host_totals, "counts": all_counts, "keypoints": all_kp, "descriptors": all_desc}
+
+
+class ResultExchange:
+    """Per-step all-gather of a frame stream's packed results without a host synchronisation inside the step."""
+
+    def __init__(self, kp_capacity: int, desc_capacity: int, group=None, headroom: float = 1.25, quantum: int = 1024):
+        self.kp_capacity, self.desc_capacity = int(kp_capacity), int(desc_capacity)
+        self.group, self.headroom, self.quantum = group, float(headroom), int(quantum)
+        self.send_kp: Optional[int] = None               # records per rank in the payload gathers (None: not yet known)
+        self.send_desc: Optional[int] = None
+        self._pending = None                             # (step, host totals tensor, event or None, send_kp, send_desc)
+        self.step = 0
+        self.incomplete_steps: List[int] = []            # steps whose payload gathers were smaller than some rank's counts
+        self.overflow_steps: List[int] = []              # steps in which some rank reported list overflow (d_totals[2])
+
+    def _round(self, n: int, cap: int) -> int:
+        n = int(n * self.headroom) + 1
+        n = (n + self.quantum - 1) // self.quantum * self.quantum
+        return max(1, min(n, cap))
+
+    def _resolve_pending(self):
+        """Reads the counts of the previous step (its collectives finished long ago: the current step's kernels were
+        enqueued behind them before this is called) and re-sizes the payload gathers."""
+        if self._pending is None:
+            return
+        step, host, ev, sent_kp, sent_desc = self._pending
+        self._pending = None
+        if ev is not None:
+            ev.synchronize()
+        mk, md = int(host[:, 0].max()), int(host[:, 1].max())
+        if mk > sent_kp or md > sent_desc:
+            self.incomplete_steps.append(step)
+        if int(host[:, 2].max()) != 0:
+            self.overflow_steps.append(step)
+        self.send_kp = self._round(max(mk, 1), self.kp_capacity)
+        self.send_desc = self._round(max(md, 1), self.desc_capacity)
+
+    def gather(self, kp_bytes: torch.Tensor, desc_bytes: torch.Tensor, counts: torch.Tensor, totals: torch.Tensor) -> Dict[str, object]:
+        world = dist.get_world_size(self.group)
+        all_totals = torch.empty((world, TOTALS), dtype=torch.int32, device=totals.device)
+        dist.all_gather_into_tensor(all_totals, _totals_row(totals), group=self.group)
+        self._resolve_pending()
+        if self.send_kp is None:                         # first step: nothing to size from -> one synchronous read
+            host = all_totals.cpu()
+            self.send_kp = self._round(max(int(host[:, 0].max()), 1), self.kp_capacity)
+            self.send_desc = self._round(max(int(host[:, 1].max()), 1), self.desc_capacity)
+        n_kp, n_desc = self.send_kp, self.send_desc
+        all_counts, all_kp, all_desc = _payload_gathers(kp_bytes, desc_bytes, counts, n_kp, n_desc, self.group)
+        if all_totals.is_cuda:
+            host = torch.empty((world, TOTALS), dtype=torch.int32, pin_memory=True)
+            host.copy_(all_totals, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = all_totals.clone(), None
+        self._pending = (self.step, host, ev, n_kp, n_desc)
+        self.step += 1
+        return {"totals_device": all_totals, "counts": all_counts, "keypoints": all_kp, "descriptors": all_desc,
+                "records_per_rank": (n_kp, n_desc)}
+
+    def finish(self):
+        """Resolve the last step's counts (end of stream); returns (incomplete_steps, overflow_steps)."""
+        self._resolve_pending()
+        return list(self.incomplete_steps), list(self.overflow_steps)

@@ -20,8 +20,9 @@ class FrameStream:
         self.kp = torch.empty(self.kp_cap * smdist.KP_BYTES, dtype=torch.uint8, device=device)
         self.desc = torch.empty(self.desc_cap * smdist.DESC_BYTES, dtype=torch.uint8, device=device)
         self.counts = torch.zeros((2, frames_per_step, engine.n_octaves), dtype=torch.int32, device=device)
-        self.totals = torch.zeros(2, dtype=torch.int32, device=device)
+        self.totals = torch.zeros(4, dtype=torch.int32, device=device)      # {n_kp, n_desc, overflow flags, 0}
         self.gathered = None
+        self.exchange = smdist.ResultExchange(self.kp_cap, self.desc_cap)
         self.launch_stream = torch.cuda.Stream(device=device)
 
     def run(self, d_frames):
@@ -42,13 +43,21 @@ class FrameStream:
                                               self.counts.data_ptr(), self.totals.data_ptr(), self.launch_stream.cuda_stream)
         cur.wait_stream(self.launch_stream)
 
-    def all_gather(self):
-        self.gathered = smdist.gather_results(self.kp, self.desc, self.counts, self.totals)
+    def all_gather(self, synchronous=False):
+        """RCCL all-gather of this step's packed results.  Default: payload sizes come from the previous step's counts, so
+        nothing synchronises the host inside the step (ResultExchange); synchronous=True sizes them from this step's."""
+        if synchronous:
+            self.gathered = smdist.gather_results(self.kp, self.desc, self.counts, self.totals)
+        else:
+            self.gathered = self.exchange.gather(self.kp, self.desc, self.counts, self.totals)
         return self.gathered
 
-    def results_host(self):
+    def results_host(self, allow_capacity=False):
         tot = self.totals.cpu().numpy()
         nk, nd = int(tot[0]), int(tot[1])
+        if tot[2] and not allow_capacity:       # the condition the host-facing API reports as SIFTMI_E_CAPACITY
+            raise _capi.SiftmiError(_capi.E_CAPACITY, "list capacity exceeded on the device path (overflow flags 0x%x): results truncated" % int(tot[2]))
         kp = self.kp[:nk * smdist.KP_BYTES].cpu().numpy().view(_capi.keypoint_dtype)
         ds = self.desc[:nd * smdist.DESC_BYTES].cpu().numpy().view(_capi.descriptor_dtype)
-        return {"n_keypoints": nk, "n_descriptors": nd, "keypoints": kp, "descriptors": ds, "counts": self.counts.cpu().numpy()}
+        return {"n_keypoints": nk, "n_descriptors": nd, "keypoints": kp, "descriptors": ds, "counts": self.counts.cpu().numpy(),
+                "overflow_flags": int(tot[2])}

@@ -8,7 +8,6 @@
 #include <cstring>
 #include <vector>
 #include "dense_kernels.hip.h"
-#include "experimental_stream_blur.hip.h"
 using namespace siftmi;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -35,7 +34,7 @@ static int gw(float s, TapWeights &out) {
     return size;
 }
 
-struct Ctx { float *src, *dst, *ref, *tmp; int w, h, nf; size_t n; };
+struct Ctx { float *src, *dst, *ref, *tmp; void *diag; int w, h, nf; size_t n; };
 
 static const char *g_filter = nullptr; static int g_rfilter = 0;
 template <typename F>
@@ -72,33 +71,33 @@ static void bench_R(Ctx &c, float rho) {
     hipLaunchKernelGGL(naive_y, g, dim3(256), 0, 0, c.tmp, c.ref, c.w, c.h, wt, n);
     CHECK(hipDeviceSynchronize());
     SeedSource none; memset(&none, 0, sizeof(none)); Decimate nodec; memset(&nodec, 0, sizeof(nodec));
-#define V2(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
-        dim3 grid((c.w + G::TW - 1) / G::TW, (c.h + G::TH - 1) / G::TH, c.nf); \
-        run_variant("v2 TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " kch=" #KCH_, c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec); }); }
+    Activity noact{nullptr, 0, 0, 0.0f};
+    // round-1 shipping kernels for reference: tile form and marching form (S = 16, carry copy)
 #define V2X(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
         const int total = ((c.w + G::TW - 1) / G::TW) * ((c.h + G::TH - 1) / G::TH) * c.nf; \
         dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("v2x TH=" #TH_ " thr=" #NTHR_ " RB=" #RB_ " minw=" #MINW_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec); }); }
+        run_variant("tile TH=" #TH_ " RB=" #RB_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec); }); }
     V2X(32, 256, 4, 1, 0)
 #define VM(SPC_, MINW_, S_) { using G = MarchGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
+        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec, noact); }); }
     VM(8, 4, 16)
-#define VMX(SPC_, MINW_, S_, NTHR_, ABL_) { using G = MarchGeom<R, S_, NTHR_>; \
-        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
+    // round 2: ring form
+#define VR(S_, CHR_, MINW_, DBG_) { using G = RingGeom<R, S_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_ " thr=" #NTHR_ " ABL=" #ABL_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, false, NTHR_, ABL_>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
-    VMX(8, 4, 16, 256, 0)
-#define VMW(SPC_, MINW_, S_, TW_, ABL_) { using G = MarchGeom<R, S_, 256, TW_>; \
-        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
-        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_ " TW=" #TW_ " ABL=" #ABL_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_, false, false, 256, ABL_, TW_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec); }); }
-#define VMS(MINW_, VSB_) { using G = MarchGeom<R, 16, 256, 128>; \
-        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + 8 * G::S - 1) / (8 * G::S); \
-        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march S=16 spc=8 minw=" #MINW_ " vsb=" #VSB_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, 16, false, false, 256, 0, 128, VSB_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, 8, nodec); }); }
-    VMS(4, 0) VMS(4, 2) VMS(4, 8) VMS(3, 0)
+        Activity dbg{(unsigned char *)c.diag, 0, 0, 0.0f}; \
+        if ((DBG_) & 1) CHECK(hipMemset(c.diag, 0, (size_t)grid.x * 4 * 8 * 8)); \
+        run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " dbg=" #DBG_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, DBG_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, dbg); }); \
+        if ((DBG_) & 1) { std::vector<unsigned long long> d((size_t)total * 32); CHECK(hipMemcpy(d.data(), c.diag, d.size() * 8, hipMemcpyDeviceToHost)); \
+            double sum[8] = {0}; for (size_t i = 0; i < d.size(); i++) sum[i & 7] += (double)d[i]; double tot = 0; for (int k = 0; k < 8; k++) tot += sum[k]; \
+            const char *nm[8] = {"issue", "H", "B2wait", "V", "stores", "B3wait", "vmwait+ldsw", "B1wait"}; \
+            printf("      stamps (cycles per wave-step, share):"); for (int k = 0; k < 8; k++) printf(" %s %.0f (%.0f%%)", nm[k], sum[k] / ((double)tx * c.nf * ((c.h + S_ - 1) / S_) * 4) , 100.0 * sum[k] / tot); printf("\n"); } }
+    VR(32, 128, 4, 0) VR(32, 256, 4, 0) VR(32, 2176, 4, 0)
+    VR(32, 256, 4, 1) VR(32, 2176, 4, 1)
+    VR(32, 256, 4, 2) VR(32, 2176, 4, 2) VR(32, 256, 4, 4) VR(32, 2176, 4, 4) VR(32, 256, 4, 6) VR(32, 2176, 4, 6)
+    VR(32, 256, 4, 8) VR(32, 2176, 4, 8) VR(32, 256, 4, 16) VR(32, 2176, 4, 16) VR(32, 256, 4, 24) VR(32, 2176, 4, 24) VR(32, 256, 4, 30) VR(32, 2176, 4, 30)
 }
 
 int main(int argc, char **argv) {
@@ -107,7 +106,7 @@ int main(int argc, char **argv) {
     if (argc > 4) g_rfilter = atoi(argv[4]);
     if (argc > 5) g_filter = argv[5];
     CHECK(hipMalloc(&c.src, c.n * c.nf * 4)); CHECK(hipMalloc(&c.dst, c.n * c.nf * 4));
-    CHECK(hipMalloc(&c.ref, c.n * c.nf * 4)); CHECK(hipMalloc(&c.tmp, c.n * c.nf * 4));
+    CHECK(hipMalloc(&c.ref, c.n * c.nf * 4)); CHECK(hipMalloc(&c.tmp, c.n * c.nf * 4)); CHECK(hipMalloc(&c.diag, 64u << 20));
     std::vector<float> h(c.n * c.nf);
     unsigned s = 12345; for (auto &v : h) { s = s * 1664525u + 1013904223u; v = (s >> 8) * (1.0f / 16777216.0f); }
     CHECK(hipMemcpy(c.src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
