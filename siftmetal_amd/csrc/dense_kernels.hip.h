@@ -611,6 +611,16 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) volatile f32x2 lds_cv_f32x2;
 
+// max of a non-negative value over the 16 lanes of a DPP row, valid in the row's lane 15 (row_shr 1, 2, 4, 8: lane i ends
+// with the max over lanes i-15 ... i; lanes without a source keep their own value).  Pure VALU: __shfl_xor goes through
+// the LDS crossbar (ds_swizzle / ds_bpermute) and this runs once per horizontal-pass item.
+__device__ __forceinline__ float row16_max_to_lane15(float e) {
+#define SIFTMI_DPP_MAX(ctrl) e = fmaxf(e, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, e), ctrl, 0xf, 0xf, false)))
+    SIFTMI_DPP_MAX(0x111); SIFTMI_DPP_MAX(0x112); SIFTMI_DPP_MAX(0x114); SIFTMI_DPP_MAX(0x118);
+#undef SIFTMI_DPP_MAX
+    return e;
+}
+
 // Register prefetch and s_waitcnt: the S new rows of step st+1 are requested at the start of step st and written to LDS
 // at its end.  hipcc counts outstanding vector-memory operations per basic block and merges conservatively at joins, so
 // every branch around a store (row / column guards) between the loads and their use made it wait for vmcnt(0) there --
@@ -752,11 +762,9 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             *reinterpret_cast<float4 *>(rowp + RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             if (ACT) {                                      // max |hb - raw| over this row's 64-column cell (16 lanes x 4 columns)
                 constexpr int C = RP - 4 * M0;
-                float e = fmaxf(fmaxf(fabsf(acc[0] - v[C + 0]), fabsf(acc[1] - v[C + 1])),
-                                fmaxf(fabsf(acc[2] - v[C + 2]), fabsf(acc[3] - v[C + 3])));
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) e = fmaxf(e, __shfl_xor(e, off, 16));
-                if ((tid & 15) == 0) ehm(slot, (tid >> 4) & 1) = e;
+                const float e = row16_max_to_lane15(fmaxf(fmaxf(fabsf(acc[0] - v[C + 0]), fabsf(acc[1] - v[C + 1])),
+                                                          fmaxf(fabsf(acc[2] - v[C + 2]), fabsf(acc[3] - v[C + 3]))));
+                if ((tid & 15) == 15) ehm(slot, (tid >> 4) & 1) = e;
             }
         }
         stamp(1);
@@ -788,6 +796,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             // pin the accumulators: otherwise LLVM sinks each row's FMA chain into the store guards below
 #pragma unroll
             for (int rr = 0; rr < RB; rr++) asm volatile("" : "+v"(acc[rr].x), "+v"(acc[rr].y));
+            unsigned act_mask = 0;                          // wave-uniform: bit rr / RB + rr = cell 0 / 1 of output row rr is active
             stamp(3);
             const int gx = x0 + 2 * lane;
 #pragma unroll
@@ -810,12 +819,17 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                     const int slot_c = (st * S + wv * RB + rr - R + NR) & (NR - 1);           // ring row under this output row
                     const float eh = ehm(slot_c, half);
                     const float lim = act.thr * 0.9999f;
-                    const bool f = (gx + 0 < w && fabsf(acc[rr].x - cen[rr].x) + eh > lim) || (gx + 1 < w && fabsf(acc[rr].y - cen[rr].y) + eh > lim);
+                    const bool f = ((FAST || gx + 0 < w) && fabsf(acc[rr].x - cen[rr].x) + eh > lim) ||
+                                   ((FAST || gx + 1 < w) && fabsf(acc[rr].y - cen[rr].y) + eh > lim);
                     const unsigned long long b = __ballot(f);
-                    const int cell = (x0 >> 6) + half;
-                    if ((lane & 31) == 0 && cell < act.ncell)
-                        act.dst[(size_t)frame * act.frame_stride + (size_t)gy * act.ncell + cell] = ((b >> (lane & 32)) & 0xffffffffull) ? 1 : 0;
+                    act_mask |= (((unsigned)b != 0u) ? 1u : 0u) << rr | (((unsigned)(b >> 32) != 0u) ? 1u : 0u) << (RB + rr);
                 }
+            }
+            if (ACT) {                                      // one store for the wave's RB rows x 2 cells: lanes 0 ... RB-1 and 32 ... 32+RB-1
+                const int half = lane >> 5, rr = lane & 31;
+                const int gy = y0 + wv * RB + rr, cell = (x0 >> 6) + half;
+                if (rr < RB && gy < h && cell < act.ncell)
+                    act.dst[(size_t)frame * act.frame_stride + (size_t)gy * act.ncell + cell] = (unsigned char)((act_mask >> (half * RB + rr)) & 1u);
             }
         }
         stamp(4);

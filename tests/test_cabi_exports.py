@@ -82,3 +82,22 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "sift_oracle" not in txt, f
+
+
+def test_swift_stub_files_match_integration_md():
+    """The reference-side binding (swift/) is committed as files; INTEGRATION.md quotes them verbatim."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```(\w*)\n(.*?)```", txt, re.S)
+    modmap = [b for lang, b in blocks if b.startswith("module CSiftmi")]
+    swift = [b for lang, b in blocks if lang == "swift"]
+    assert len(modmap) == 1 and len(swift) == 2
+    sw = os.path.join(ROOT, "swift", "Sources")
+    assert open(os.path.join(sw, "CSiftmi", "module.modulemap")).read() == modmap[0]
+    assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X.swift")).read() == swift[0]
+    assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Match.swift")).read() == "import CSiftmi\n\n" + swift[1]
+    # every siftmi_* symbol the Swift uses is declared in the header
+    hdr = open(os.path.join(ROOT, "include", "siftmi.h")).read()
+    used = set(re.findall(r"\b(siftmi_[a-z_0-9]+)\s*\(", swift[0] + swift[1]))
+    assert used and all(re.search(r"\b%s\s*\(" % u, hdr) for u in used - {"siftmi_config", "siftmi_keypoint", "siftmi_descriptor"}), used
+    man = open(os.path.join(ROOT, "swift", "Package.swift")).read()
+    assert '.systemLibrary(name: "CSiftmi"' in man and '.linkedLibrary("siftmi")' in man

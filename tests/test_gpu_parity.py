@@ -580,3 +580,103 @@ def test_graph_replays_stay_correct(sm, frames, lockstep):
         np.testing.assert_array_equal(r["counts"][0], kc)
         np.testing.assert_array_equal(r["counts"][1], dc)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: 64 x 1920x1080, lock-step 32, hipGraph replay -- against a lock-step-1 engine and the oracle
+
+def _frame_slices(counts, f):
+    """(keypoint slice, descriptor slice) of frame f in the packed (frame, octave)-ordered outputs."""
+    kc, dc = counts[0].reshape(counts.shape[1], -1), counts[1].reshape(counts.shape[1], -1)
+    k0, d0 = int(kc[:f].sum()), int(dc[:f].sum())
+    return slice(k0, k0 + int(kc[f].sum())), slice(d0, d0 + int(dc[f].sum()))
+
+
+def test_config2_64x1080p_lockstep32_graph_replays_equal_lockstep1(sm):
+    """The bench workload itself: FrameStream over 64 x 1920x1080 frames (8 distinct), lock-step 32 (marching ring blur
+    with activity flags on octaves 0 and 1, flagged-row extrema scan), direct launches on the first call, capture on the
+    second, then two replays: every frame's records of every run are bit-equal to what a lock-step-1 engine (tile /
+    small-launch paths, full extrema scan) returns for that frame."""
+    import torch
+    from siftmetal_amd import stream as smstream
+    dev = torch.device("cuda", 0)
+    W, H, F = 1920, 1080, 64
+    base = [blob_frame(W, H, i) for i in range(8)]
+    one = sm.Engine(W, H, n_octaves=4, max_batch=1)
+    want = [one.detect_describe_batch(b[None]) for b in base]
+    one.close()
+    frames = np.stack([base[i % 8] for i in range(F)])
+    eng = sm.Engine(W, H, n_octaves=4, max_batch=32)
+    fs = smstream.FrameStream(eng, F, device=dev)
+    d = torch.from_numpy(frames).to(dev)
+    for run in range(4):
+        fs.run(d)
+        torch.cuda.synchronize()
+        r = fs.results_host()
+        assert r["overflow_flags"] == 0
+        for f in range(F):
+            wk, wkc, wd, wdc = want[f % 8]
+            assert np.array_equal(r["counts"][0][f], wkc[0]) and np.array_equal(r["counts"][1][f], wdc[0]), (run, f)
+            ks, dsl = _frame_slices(r["counts"], f)
+            assert r["keypoints"][ks].tobytes() == wk.tobytes(), (run, f)
+            assert r["descriptors"][dsl].tobytes() == wd.tobytes(), (run, f)
+    st = eng.stats()                                       # statistics of a device-resident call, fetched lazily
+    assert st["keypoints"].shape == (F, 4) and not st["raw_extrema_exact"]
+    assert np.array_equal(st["keypoints"], r["counts"][0]) and np.array_equal(st["descriptors"], r["counts"][1])
+    eng.close()
+
+
+@pytest.mark.parametrize("which", ["blob0", "blob5", "dense"])
+def test_1080p_marching_path_stage_by_stage_vs_oracle(sm, butterfly_bgra, which):
+    """1920x1080 / 4 octaves with EVERY layer of every octave through the marching ring blur + flagged-row extrema scan
+    (blur_march_min_blocks = 1): every stage against the oracle, on two benchmark frames and on the dense natural-texture
+    frame."""
+    img = _natural_1080p(butterfly_bgra) if which == "dense" else blob_frame(1920, 1080, int(which[4:]))
+    rep = parity.check_full_path(sm, img, 4, 3, blur_march_min_blocks=1)
+    assert rep["keypoints"] > (10000 if which == "dense" else 1500)
+
+
+def test_dog_readback_matches_oracle(sm, butterfly_bgra):
+    """siftmi_copy_dog: the DoG textures the reference's DifferenceOfGaussians exposes (Subtract.metal:12-21)."""
+    eng = sm.Engine(512, 340, n_octaves=4)
+    eng.detect(butterfly_bgra)
+    orc = _oracle(512, 340, 4)
+    orc.build_pyramid(butterfly_bgra)
+    for o in range(4):
+        for s in range(5):
+            assert np.array_equal(eng.dog(o, s), orc.dog(o, s)), (o, s)
+    with pytest.raises(sm.SiftmiError):
+        eng.dog(0, 5)
+    eng.close()
+
+
+def test_device_path_reports_overflow_and_orders_following_calls(sm):
+    """the device-resident call must surface list overflow (d_totals[2]) instead of truncating silently, and a
+    following call on the context's own stream must be ordered after it (shared scratch)."""
+    import torch
+    from siftmetal_amd import _capi, stream as smstream
+    dev = torch.device("cuda", 0)
+    frames = np.stack([blob_frame(640, 480, i) for i in range(3)])
+    small = sm.Engine(640, 480, n_octaves=3, max_batch=2, max_keypoints=16, max_descriptors=16)
+    fs = smstream.FrameStream(small, 3, device=dev)
+    fs.run(torch.from_numpy(frames).to(dev))
+    with pytest.raises(sm.SiftmiError) as e:
+        fs.results_host()
+    assert e.value.code == _capi.E_CAPACITY
+    r = fs.results_host(allow_capacity=True)
+    assert r["overflow_flags"] & 2 and r["counts"].max() <= 16
+    small.close()
+    # ordering: device call on a side stream, then introspection + a host-facing call on the context's stream, no explicit sync
+    eng = sm.Engine(640, 480, n_octaves=3, max_batch=3)
+    want = eng.detect_describe_batch(frames)
+    g_want = eng.gaussian(1, 3, frame=2)
+    fs = smstream.FrameStream(eng, 3, device=dev)
+    d = torch.from_numpy(frames).to(dev)
+    for _ in range(3):
+        fs.run(d)
+        assert np.array_equal(eng.gaussian(1, 3, frame=2), g_want)          # waits for the device call
+        k, kc, ds, dc = eng.detect_describe_batch(frames[::-1].copy())      # re-uses the scratch on the context's stream
+        assert kc.sum() == want[1].sum()
+        r = fs.results_host()
+        assert r["keypoints"].tobytes() == want[0].tobytes() and r["descriptors"].tobytes() == want[2].tobytes()
+    eng.close()
