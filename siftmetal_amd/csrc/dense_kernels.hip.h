@@ -80,18 +80,36 @@ struct SeedSource {                 // input frame description for the seed load
     int in_w, in_h;                 // input size (W, H); the seed image is 2W x 2H
 };
 
-// luma of input pixel (x, y): ConvertSRGBToGrayscale.metal:17-20 on bgra8Unorm texels (byte/255)
+// byte / 255 (a bgra8Unorm texel), correctly rounded like the IEEE division it replaces: q = x * fl(1/255) followed by one
+// residual correction gives fl(x / 255) for every byte value (all 256 checked in tests/test_oracle_golden.py) in 3 VALU
+// operations; the division sequence takes ~10.
+__device__ __forceinline__ float unorm8(unsigned b) {
+    const float x = (float)b, r = 0.003921568859368563f;
+    const float q = x * r;
+    return fmaf(fmaf(-q, 255.0f, x), r, q);
+}
+
+// luma from the raw 32 bits of a pixel: ConvertSRGBToGrayscale.metal:17-20 on bgra8Unorm texels (FMT_BGRA8), a byte / 255
+// (FMT_GRAY8), or the float itself
+__device__ __forceinline__ float luma_of(int format, unsigned raw) {
+    if (format == FMT_BGRA8) {
+        const float b = unorm8(raw & 255u), g = unorm8((raw >> 8) & 255u), r = unorm8((raw >> 16) & 255u);
+        return 0.0f + (0.212639005871510f * r) + (0.715168678767756f * g) + (0.072192315360734f * b);
+    } else if (format == FMT_GRAY8) {
+        return unorm8(raw & 255u);
+    }
+    return __uint_as_float(raw);
+}
+__device__ __forceinline__ unsigned raw_pixel(int format, const unsigned char *frame, const SeedSource &s, int x, int y) {   // in range
+    const unsigned char *row = frame + (size_t)y * s.row_stride;
+    if (format == FMT_GRAY8) return row[x];
+    return *reinterpret_cast<const unsigned *>(row + 4 * (size_t)x);
+}
+
+// luma of input pixel (x, y), 0 outside the image
 __device__ __forceinline__ float luma_at(const unsigned char *frame, const SeedSource &s, int x, int y) {
     if (x < 0 || y < 0 || x >= s.in_w || y >= s.in_h) return 0.0f;
-    const unsigned char *row = frame + (size_t)y * s.row_stride;
-    if (s.format == FMT_BGRA8) {
-        const uchar4 p = *reinterpret_cast<const uchar4 *>(row + 4 * (size_t)x);
-        const float b = (float)p.x / 255.0f, g = (float)p.y / 255.0f, r = (float)p.z / 255.0f;
-        return 0.0f + (0.212639005871510f * r) + (0.715168678767756f * g) + (0.072192315360734f * b);
-    } else if (s.format == FMT_GRAY8) {
-        return (float)row[x] / 255.0f;
-    }
-    return reinterpret_cast<const float *>(row)[x];
+    return luma_of(s.format, raw_pixel(s.format, frame, s, x, y));
 }
 
 // BilinearUpScale.metal:24-61 at output pixel (i, j) of the wo x ho = 2W x 2H image
@@ -631,12 +649,22 @@ __device__ __forceinline__ float row16_max_to_lane15(float e) {
 // DBG (tools/ubench only; 0 in the library): 1 = s_memtime stamps per phase, summed per wavefront into the buffer passed as
 // act.dst ([workgroup][wave][8] u64); 2 = no global stores, 4 = no global loads, 8 = no horizontal-pass arithmetic,
 // 16 = no vertical-pass arithmetic (timing ablations, wrong results).
-template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0>
+// SEEDF >= 0: the seed layer (octave 0, layer 0).  `src` is unused; the rows a step stages are the 2x bilinear upscale
+// (BilinearUpScale.metal:24-61) of the luma (ConvertSRGBToGrayscale.metal:17-20) of the input frame, pixel format SEEDF.
+// A step's S new rows need at most S/2 + 2 input rows x LW/2 + 4 input columns: their raw pixels are prefetched like the
+// float rows of a layer blur (6 dwords per lane instead of 18 floats), turned into luma ONCE per input pixel into a tile
+// that borrows the dead rows of the current ring half, and expanded from there into the ring rows (an even output row /
+// column is a luma row / column exactly, an odd one the 0.5 / 0.5 blend, in the reference's expression order).
+template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1>
 __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
-                                                             int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act) {
+                                                             int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
+                                                             SeedSource seed) {
     using G = RingGeom<R, S_>;
     constexpr int NR = G::NR, LW = G::LW, RP = G::RP, S = G::S, RB = G::RB;
+    constexpr bool SEED = SEEDF >= 0;
+    constexpr int TLW = LW / 2 + 4, TLH = S / 2 + 2, NPX = (TLW * TLH + G::NTHR - 1) / G::NTHR;   // luma tile of a step (input pixels)
+    static_assert(!SEED || (TLW * TLH <= (S - 2 * R) * LW && !DEC && !ACT), "the luma tile borrows the dead rows of a ring half");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // max|Eh| of (ring row, cell): only with ACT (see RingGeom::EHM_IN_ROW)
     auto ehm = [&](int slot, int cell) -> float & { return G::EHM_IN_ROW ? lds[slot * LW + cell] : lds[LW * NR + slot * 2 + cell]; };
@@ -654,15 +682,18 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
     const int chunk = rem / tx, bx = rem - chunk * tx;
     const int x0 = bx * G::TW, ybeg = chunk * ch_rows;
     const int nst = (min(ch_rows, h - ybeg) + S - 1) / S;   // steps of this chunk
-    const float *__restrict__ in = src + (size_t)frame * src_frame_stride;
+    const float *__restrict__ in = SEED ? nullptr : src + (size_t)frame * src_frame_stride;
     float *__restrict__ out = dst + (size_t)frame * dst_frame_stride;
+    const unsigned char *px = SEED ? seed.pixels + (size_t)frame * seed.frame_stride : nullptr;
     // general staging of rows u in [u0, u1) (mirror resolved per element)
     auto stage_rows = [&](int u0, int u1) {
         for (int idx = tid; idx < (u1 - u0) * LW; idx += G::NTHR) {
             const int lu = idx / LW, lx = idx - lu * LW;
             const int slot = (u0 + lu + NR) & (NR - 1);
             const int sx = symm(x0 - RP + lx, w), sy = symm(ybeg + R + u0 + lu, h);
-            lds[slot * LW + lx] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : in[(size_t)sy * w + sx];
+            float v = 0.0f;
+            if (sx >= 0 && sy >= 0 && sx < w && sy < h) v = SEED ? seed_sample(px, seed, sx, sy, w, h) : in[(size_t)sy * w + sx];
+            lds[slot * LW + lx] = v;
         }
     };
     // Row loads of the fast path.  8 lanes per row: lane q of a row takes the float4 columns q + 8 j (j < NPF4) and, when
@@ -698,9 +729,74 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         if (G::REM) *reinterpret_cast<f32x2 *>(rowp + 32 * G::NPF4 + 2 * pf_q) = rem;
     };
 
+    // Seed loader (SEED only).  Tile = luma of input rows ilo ... ilo + TLH - 1, columns clo ... clo + TLW - 1 (clamped to the
+    // image: a clamped duplicate is never read, or is the mirrored neighbour BilinearUpScale.metal:33-48 asks for).
+    const int wi = seed.in_w, hi = seed.in_h, clo = max(0, (x0 - RP) >> 1);
+    auto tile_first_row = [&](int ya, int n) {              // lowest input row under output rows ya ... ya + n - 1 (mirrored)
+        return (ya < 0 && ya + n > 0) ? 0 : min(symm(ya, h) >> 1, symm(ya + n - 1, h) >> 1);
+    };
+    auto load_pixels = [&](int ilo, unsigned (&raw)[NPX]) {
+#pragma unroll
+        for (int k = 0; k < NPX; k++) {
+            const int idx = min(tid + k * G::NTHR, TLW * TLH - 1);
+            const int r = idx / TLW, c = idx - r * TLW;
+            raw[k] = raw_pixel(SEEDF, px, seed, min(clo + c, wi - 1), min(ilo + r, hi - 1));
+        }
+    };
+    auto write_tile = [&](float *tile, const unsigned (&raw)[NPX]) {
+#pragma unroll
+        for (int k = 0; k < NPX; k++) tile[min(tid + k * G::NTHR, TLW * TLH - 1)] = luma_of(SEEDF, raw[k]);
+    };
+    auto expand_rows = [&](const float *tile, int ilo, int ya, int n, int u_first) {      // tile -> ring rows u_first + (0 ... n-1)
+        const int lr = min(pf_row, n - 1);
+        const int sy = symm(ya + lr, h);
+        const int jm = sy >> 1, jp = min(jm + 1, hi - 1);   // BilinearUpScale.metal:29-48 for the exact 2x case
+        const bool odd = (sy & 1) != 0;                     // fy = 0.5 (odd rows) or 0
+        const float *tm = tile + (jm - ilo) * TLW - clo, *tp = tile + (jp - ilo) * TLW - clo;
+        // vertical blend of input column c: fy * L(c, jp) + (1 - fy) * L(c, jm); with fy = 0 that is L(c, jm) exactly
+        auto A = [&](int c) { const float cm = tm[c], cp = tp[c]; return odd ? 0.5f * cp + 0.5f * cm : cm; };
+        float *rowp = lds + ((u_first + lr + NR) & (NR - 1)) * LW;
+#pragma unroll
+        for (int j = 0; j < G::NPF4; j++) {
+            const int gx = x0 - RP + 4 * pf_q + 32 * j;
+            const bool mir = gx < 0 || gx >= w;
+            const int g2 = gx < 0 ? -gx - 4 : (gx >= w ? 2 * w - 4 - gx : gx);
+            const int c0 = g2 >> 1;
+            const float a0 = A(c0), a1 = A(c0 + 1), a2 = A(min(c0 + 2, wi - 1));
+            // even column: fx = 0 -> A(im); odd column: fx * A(ip) + (1 - fx) * A(im) with fx = 0.5
+            const float o0 = a0, o1 = 0.5f * a1 + 0.5f * a0, o2 = a1, o3 = 0.5f * a2 + 0.5f * a1;
+            f32x4 o;
+            o.x = mir ? o3 : o0; o.y = mir ? o2 : o1; o.z = mir ? o1 : o2; o.w = mir ? o0 : o3;
+            *reinterpret_cast<f32x4 *>(rowp + 4 * pf_q + 32 * j) = o;
+        }
+        if (G::REM) {
+            const int gx = x0 - RP + 32 * G::NPF4 + 2 * pf_q;
+            const bool mir = gx >= w;
+            const int c0 = (mir ? 2 * w - 2 - gx : gx) >> 1;
+            const float a0 = A(c0), a1 = A(min(c0 + 1, wi - 1));
+            const float o0 = a0, o1 = 0.5f * a1 + 0.5f * a0;
+            f32x2 o;
+            o.x = mir ? o1 : o0; o.y = mir ? o0 : o1;
+            *reinterpret_cast<f32x2 *>(rowp + 32 * G::NPF4 + 2 * pf_q) = o;
+        }
+    };
+
     // prologue: rows u in [-2R, S) of the first step.  Fast path: every load of both batches in flight before the first
     // LDS write (a load -> wait -> write loop cost nine memory latencies per chunk, as long as five steps).
-    if (colfast) {
+    if (colfast && SEED) {
+        float *tile = lds + S * LW;                          // rows S ... of the ring: written by neither pass
+        unsigned ra[NPX], rb[NPX];
+        const int ia = tile_first_row(ybeg - R, S), ib = tile_first_row(ybeg - R + S, 2 * R);
+        load_pixels(ia, ra);
+        load_pixels(ib, rb);
+        write_tile(tile, ra);
+        lds_barrier();
+        expand_rows(tile, ia, ybeg - R, S, -2 * R);
+        lds_barrier();
+        write_tile(tile, rb);
+        lds_barrier();
+        expand_rows(tile, ib, ybeg - R + S, 2 * R, S - 2 * R);
+    } else if (colfast) {
         f32x4 a[G::NPF4], b[G::NPF4];
         f32x2 ar, br;
         load_rows(ybeg - R, S, a, ar);
@@ -731,10 +827,16 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         stamp(7);
         f32x4 pf[G::NPF4];
         f32x2 pfr;
+        unsigned raw[NPX];
+        int tile_row0 = 0;
         if (FAST && (DBG & 4)) {
 #pragma unroll
             for (int j = 0; j < G::NPF4; j++) pf[j] = f32x4{1.0f, 2.0f, 3.0f, (float)j};
             pfr = f32x2{1.0f, 2.0f};
+        } else
+        if (FAST && SEED) {                                  // the input pixels under the next step's S new rows -> registers
+            tile_row0 = tile_first_row(ybeg + R + (st + 1) * S, S);
+            load_pixels(tile_row0, raw);
         } else
         if (FAST) load_rows(ybeg + R + (st + 1) * S, S, pf, pfr);   // the next step's S new rows -> registers, all lanes alike
 
@@ -836,6 +938,12 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         if (!has_next) return;                               // uniform
         lds_barrier();                                       // B3: every read of the other ring half is done
         stamp(5);
+        if (FAST && SEED) {
+            float *tile = lds + ((st & 1) * S) * LW;         // first S - 2R rows of the current half: no later step reads them
+            write_tile(tile, raw);
+            lds_barrier();
+            expand_rows(tile, tile_row0, ybeg + R + (st + 1) * S, S, (st + 1) * S);
+        } else
         if (FAST) store_rows((st + 1) * S, S, pf, pfr);
         else stage_rows((st + 1) * S, (st + 2) * S);        // general step: mirror per element, straight to LDS
         // keeps LLVM from tail-merging the LDS writes above of the two instantiations: merged, they would be reached from

@@ -471,21 +471,44 @@ template <int R, bool SEED, bool DEC>
 static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
                                  const TapWeights &wt, const SeedSource &seed, const Decimate &dec, const Activity &act) {
     bool march = false;
+    // large launches: marching form (no vertical-halo recompute beyond a chunk's prologue, next rows prefetched under
+    // the FMA phases); it needs enough strips x chunks to fill the chip, so small octaves keep the tile kernel.
+    using Gr = RingGeom<R>;
     if constexpr (!SEED) {
-        // large launches: marching form (no vertical-halo recompute beyond a chunk's prologue, next rows prefetched under
-        // the FMA phases); it needs enough strips x chunks to fill the chip, so small octaves keep the tile kernel.
-        using Gm = RingGeom<R>;
         const int chr = march_chunk_rows(h);
-        const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + chr - 1) / chr) * nf;
+        const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
         if (uses_march(c, w, h, nf)) {
             march = true;
             dim3 grid(((total + 7) / 8) * 8, 1, 1);
             if (act.dst)
-                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, true>), grid, dim3(Gm::NTHR), Gm::lds_bytes_act, st, src, dst, w, h,
-                                   c->frame_stride, c->frame_stride, wt, nf, chr, dec, act);
+                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, true>), grid, dim3(Gr::NTHR), Gr::lds_bytes_act, st, src, dst, w, h,
+                                   c->frame_stride, c->frame_stride, wt, nf, chr, dec, act, seed);
             else
-                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, false>), grid, dim3(Gm::NTHR), Gm::lds_bytes, st, src, dst, w, h, c->frame_stride,
-                                   c->frame_stride, wt, nf, chr, dec, act);
+                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, false>), grid, dim3(Gr::NTHR), Gr::lds_bytes, st, src, dst, w, h, c->frame_stride,
+                                   c->frame_stride, wt, nf, chr, dec, act, seed);
+        }
+    } else if constexpr (R >= 4 && R <= 6) {
+        // the seed layer in marching form (instantiated for the radii around the default schedule's 5; other sigma
+        // settings keep the tile kernel): longer chunks, because its prologue runs the luma / upscale expansion twice
+        const int chr = 256;
+        const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
+        if (uses_march(c, w, h, nf)) {
+            march = true;
+            dim3 grid(((total + 7) / 8) * 8, 1, 1);
+            switch (seed.format) {
+                case FMT_BGRA8:
+                    hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, false, false, 0, FMT_BGRA8>), grid, dim3(Gr::NTHR), Gr::lds_bytes, st, src, dst, w, h,
+                                       c->frame_stride, c->frame_stride, wt, nf, chr, dec, act, seed);
+                    break;
+                case FMT_GRAY8:
+                    hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, false, false, 0, FMT_GRAY8>), grid, dim3(Gr::NTHR), Gr::lds_bytes, st, src, dst, w, h,
+                                       c->frame_stride, c->frame_stride, wt, nf, chr, dec, act, seed);
+                    break;
+                default:
+                    hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, false, false, 0, FMT_GRAYF32>), grid, dim3(Gr::NTHR), Gr::lds_bytes, st, src, dst, w, h,
+                                       c->frame_stride, c->frame_stride, wt, nf, chr, dec, act, seed);
+                    break;
+            }
         }
     }
     if (!march) {

@@ -204,3 +204,22 @@ def test_gray_and_bgra_entries_agree():
     f.build_pyramid((g.astype(np.float32) / np.float32(255.0)))
     assert np.abs(a.gaussian(0, 3) - b.gaussian(0, 3)).max() < 3e-7
     assert np.array_equal(a.gaussian(0, 3), f.gaussian(0, 3))
+
+
+def test_unorm8_reciprocal_form_is_the_exact_division():
+    """dense_kernels.hip.h::unorm8 replaces byte / 255.0f by q = x * fl(1/255); q += fma(-q, 255, x) * fl(1/255).  For every
+    byte value that is the correctly rounded quotient, i.e. what the oracle's (and the reference's unorm texel) division gives."""
+    from fractions import Fraction
+
+    def fl32(fr):
+        f = np.float32(float(fr))
+        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
+        return min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1))
+
+    r = np.float32(0.003921568859368563)
+    assert r == fl32(Fraction(1, 255))
+    for x in range(256):
+        q = fl32(Fraction(x) * Fraction(float(r)))
+        e = fl32(Fraction(x) - Fraction(float(q)) * 255)
+        q2 = fl32(Fraction(float(e)) * Fraction(float(r)) + Fraction(float(q)))
+        assert q2 == np.float32(x) / np.float32(255.0) == fl32(Fraction(x, 255)), x

@@ -89,7 +89,7 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         Activity dbg{(unsigned char *)c.diag, 0, 0, 0.0f}; \
         if ((DBG_) & 1) CHECK(hipMemset(c.diag, 0, (size_t)grid.x * 4 * 8 * 8)); \
-        run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " dbg=" #DBG_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, DBG_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, dbg); }); \
+        run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " dbg=" #DBG_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, DBG_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, dbg, none); }); \
         if ((DBG_) & 1) { std::vector<unsigned long long> d((size_t)total * 32); CHECK(hipMemcpy(d.data(), c.diag, d.size() * 8, hipMemcpyDeviceToHost)); \
             double sum[8] = {0}; for (size_t i = 0; i < d.size(); i++) sum[i & 7] += (double)d[i]; double tot = 0; for (int k = 0; k < 8; k++) tot += sum[k]; \
             const char *nm[8] = {"issue", "H", "B2wait", "V", "stores", "B3wait", "vmwait+ldsw", "B1wait"}; \
