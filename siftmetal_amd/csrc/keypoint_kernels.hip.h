@@ -254,37 +254,61 @@ __device__ __forceinline__ void cross3(const float a[3], const float b[3], float
     r[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-__device__ __forceinline__ void derivatives3d(const DogTex &t, int x, int y, int s, float dD[3]) {   // :64-87
-    const float pzz = t.rd(x + 1, y, s), nzz = t.rd(x - 1, y, s);
-    const float zpz = t.rd(x, y + 1, s), znz = t.rd(x, y - 1, s);
-    const float zzp = t.rd(x, y, s + 1), zzn = t.rd(x, y, s - 1);
-    dD[0] = (pzz - nzz) * 0.5f; dD[1] = (zpz - znz) * 0.5f; dD[2] = (zzp - zzn) * 0.5f;
+// The 19 DoG values around (x, y, s) that one refinement step, the final contrast and the edge test read
+// (SIFTInterpolate.metal:17-176 read them texel by texel, three times over).  Loaded ONCE per step: for an interior
+// position the 28 Gaussian values behind them are fetched by unconditional, independent loads (one memory latency per
+// step; round 1 read each DoG value behind its own bounds test, i.e. ~50 dependent conditional loads per step, and
+// the kernel was latency-bound at 0.5 ms per launch), and a converged candidate's last step leaves everything its
+// final tests need.  Each DoG value is still the single f32 subtraction G[s+1] - G[s] (Subtract.metal:17-19).
+struct DogNeighbourhood {
+    float zzz, pzz, nzz, zpz, znz, ppz, nnz, npz, pnz;      // scale s:   centre, x+-1, y+-1, diagonals  (p = +1, n = -1, z = 0; order x y s)
+    float zzp, pzp, nzp, zpp, znp;                          // scale s+1: centre, x+-1, y+-1
+    float zzn, pzn, nzn, zpn, znn;                          // scale s-1
+};
+
+__device__ __forceinline__ void load_neighbourhood(const DogTex &t, int x, int y, int s, DogNeighbourhood &d) {
+    if (x >= 1 && y >= 1 && s >= 1 && x <= t.w - 2 && y <= t.h - 2 && s <= t.nd - 2) {
+        const float *c = t.g + (size_t)s * t.n + (size_t)y * t.w + x;       // Gaussian layer s at (x, y)
+        const int w = t.w;
+        const size_t n = t.n;
+        // Gaussian layers s-1 (5 values), s and s+1 (9 each), s+2 (5)
+        const float a_z = c[-(ptrdiff_t)n], a_p = c[-(ptrdiff_t)n + 1], a_n = c[-(ptrdiff_t)n - 1], a_zp = c[-(ptrdiff_t)n + w], a_zn = c[-(ptrdiff_t)n - w];
+        const float b_zz = c[0], b_pz = c[1], b_nz = c[-1], b_zp = c[w], b_zn = c[-w], b_pp = c[w + 1], b_nn = c[-w - 1], b_np = c[w - 1], b_pn = c[-w + 1];
+        const float *e = c + n;
+        const float c_zz = e[0], c_pz = e[1], c_nz = e[-1], c_zp = e[w], c_zn = e[-w], c_pp = e[w + 1], c_nn = e[-w - 1], c_np = e[w - 1], c_pn = e[-w + 1];
+        const float *f = e + n;
+        const float d_z = f[0], d_p = f[1], d_n = f[-1], d_zp = f[w], d_zn = f[-w];
+        d.zzz = c_zz - b_zz; d.pzz = c_pz - b_pz; d.nzz = c_nz - b_nz; d.zpz = c_zp - b_zp; d.znz = c_zn - b_zn;
+        d.ppz = c_pp - b_pp; d.nnz = c_nn - b_nn; d.npz = c_np - b_np; d.pnz = c_pn - b_pn;
+        d.zzp = d_z - c_zz; d.pzp = d_p - c_pz; d.nzp = d_n - c_nz; d.zpp = d_zp - c_zp; d.znp = d_zn - c_zn;
+        d.zzn = b_zz - a_z; d.pzn = b_pz - a_p; d.nzn = b_nz - a_n; d.zpn = b_zp - a_zp; d.znn = b_zn - a_zn;
+    } else {                                                 // at the image or scale border (only with image_border = 0): reads outside are 0
+        d.zzz = t.rd(x, y, s);
+        d.pzz = t.rd(x + 1, y, s); d.nzz = t.rd(x - 1, y, s); d.zpz = t.rd(x, y + 1, s); d.znz = t.rd(x, y - 1, s);
+        d.ppz = t.rd(x + 1, y + 1, s); d.nnz = t.rd(x - 1, y - 1, s); d.npz = t.rd(x - 1, y + 1, s); d.pnz = t.rd(x + 1, y - 1, s);
+        d.zzp = t.rd(x, y, s + 1); d.pzp = t.rd(x + 1, y, s + 1); d.nzp = t.rd(x - 1, y, s + 1); d.zpp = t.rd(x, y + 1, s + 1); d.znp = t.rd(x, y - 1, s + 1);
+        d.zzn = t.rd(x, y, s - 1); d.pzn = t.rd(x + 1, y, s - 1); d.nzn = t.rd(x - 1, y, s - 1); d.zpn = t.rd(x, y + 1, s - 1); d.znn = t.rd(x, y - 1, s - 1);
+    }
 }
 
-__device__ void interpolation_step(const DogTex &t, int x, int y, int s, float alpha[3]) {   // :90-176, Common.hpp:34-47
-    const float zzz = t.rd(x, y, s);
-    const float pzz = t.rd(x + 1, y, s), nzz = t.rd(x - 1, y, s);
-    const float zpz = t.rd(x, y + 1, s), znz = t.rd(x, y - 1, s);
-    const float zzp = t.rd(x, y, s + 1), zzn = t.rd(x, y, s - 1);
-    const float ppz = t.rd(x + 1, y + 1, s), nnz = t.rd(x - 1, y - 1, s);
-    const float npz = t.rd(x - 1, y + 1, s), pnz = t.rd(x + 1, y - 1, s);
-    const float pzp = t.rd(x + 1, y, s + 1), nzp = t.rd(x - 1, y, s + 1);
-    const float zpp = t.rd(x, y + 1, s + 1), znp = t.rd(x, y - 1, s + 1);
-    const float pzn = t.rd(x + 1, y, s - 1), nzn = t.rd(x - 1, y, s - 1);
-    const float zpn = t.rd(x, y + 1, s - 1), znn = t.rd(x, y - 1, s - 1);
-    const float dxx = pzz + nzz - 2.0f * zzz;
-    const float dyy = zpz + znz - 2.0f * zzz;
-    const float dss = zzp + zzn - 2.0f * zzz;
-    const float dxy = (ppz - npz - pnz + nnz) * 0.25f;
-    const float dxs = (pzp - nzp - pzn + nzn) * 0.25f;
-    const float dys = (zpp - znp - zpn + znn) * 0.25f;
+__device__ __forceinline__ void derivatives3d(const DogNeighbourhood &d, float dD[3]) {   // :64-87
+    dD[0] = (d.pzz - d.nzz) * 0.5f; dD[1] = (d.zpz - d.znz) * 0.5f; dD[2] = (d.zzp - d.zzn) * 0.5f;
+}
+
+__device__ __forceinline__ void interpolation_step(const DogNeighbourhood &d, float alpha[3]) {   // :90-176, Common.hpp:34-47
+    const float dxx = d.pzz + d.nzz - 2.0f * d.zzz;
+    const float dyy = d.zpz + d.znz - 2.0f * d.zzz;
+    const float dss = d.zzp + d.zzn - 2.0f * d.zzz;
+    const float dxy = (d.ppz - d.npz - d.pnz + d.nnz) * 0.25f;
+    const float dxs = (d.pzp - d.nzp - d.pzn + d.nzn) * 0.25f;
+    const float dys = (d.zpp - d.znp - d.zpn + d.znn) * 0.25f;
     const float x0[3] = {dxx, dxy, dxs}, x1[3] = {dxy, dyy, dys}, x2[3] = {dxs, dys, dss};
     float c12[3], c20[3], c01[3];
     cross3(x1, x2, c12); cross3(x2, x0, c20); cross3(x0, x1, c01);
     const float det = x0[0] * c12[0] + x0[1] * c12[1] + x0[2] * c12[2];
     const float inv = 1.0f / det;
     float dD[3];
-    derivatives3d(t, x, y, s, dD);
+    derivatives3d(d, dD);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float h0 = -1.0f * (inv * c12[k]), h1 = -1.0f * (inv * c20[k]), h2 = -1.0f * (inv * c01[k]);
@@ -292,12 +316,12 @@ __device__ void interpolation_step(const DogTex &t, int x, int y, int s, float a
     }
 }
 
-__device__ __forceinline__ bool is_on_edge(const DogTex &t, int x, int y, int s, float edgeThreshold) {   // :17-61
-    const float v = t.rd(x, y, s);
-    const float zn = t.rd(x, y - 1, s), zp = t.rd(x, y + 1, s);
-    const float pz = t.rd(x + 1, y, s), nz = t.rd(x - 1, y, s);
-    const float pp = t.rd(x + 1, y + 1, s), np = t.rd(x - 1, y + 1, s);
-    const float pn = t.rd(x + 1, y - 1, s), nn = t.rd(x - 1, y - 1, s);
+__device__ __forceinline__ bool is_on_edge(const DogNeighbourhood &d, float edgeThreshold) {   // :17-61
+    const float v = d.zzz;
+    const float zn = d.znz, zp = d.zpz;
+    const float pz = d.pzz, nz = d.nzz;
+    const float pp = d.ppz, np = d.npz;
+    const float pn = d.pnz, nn = d.nnz;
     const float hxx = zn + zp - 2.0f * v;
     const float hyy = pz + nz - 2.0f * v;
     const float hxy = ((pp - np) - (pn - nn)) * 0.25f;
@@ -342,9 +366,11 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
             bool ok = !(fabsf(value) <= prm.dog_threshold * 0.8f) && !out_of_bounds(x, y, s, w, h, P.nspo, prm.border);
             bool converged = false;
             float alpha[3] = {0.0f, 0.0f, 0.0f};
+            DogNeighbourhood nb;
             int i = 0;
             while (ok && i < prm.max_iterations) {
-                interpolation_step(t, x, y, s, alpha);
+                load_neighbourhood(t, x, y, s, nb);
+                interpolation_step(nb, alpha);
                 if (fabsf(alpha[0]) < prm.max_offset && fabsf(alpha[1]) < prm.max_offset && fabsf(alpha[2]) < prm.max_offset) {
                     converged = true;
                     break;
@@ -359,12 +385,12 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
                 i += 1;
             }
             ok = ok && converged;
-            if (ok) {
+            if (ok) {                                               // converged: nb is the neighbourhood of the final (x, y, s)
                 float dD[3];
-                derivatives3d(t, x, y, s, dD);
+                derivatives3d(nb, dD);
                 const float cx = dD[0] * alpha[0];                  // :96-99 x term only
-                value = t.rd(x, y, s) + cx * 0.5f;
-                ok = !(fabsf(value) <= prm.dog_threshold) && !is_on_edge(t, x, y, s, prm.edge_threshold);
+                value = nb.zzz + cx * 0.5f;
+                ok = !(fabsf(value) <= prm.dog_threshold) && !is_on_edge(nb, prm.edge_threshold);
             }
             if (ok) {
                 keep = true;                                        // SIFTOctave.swift:266-284
@@ -492,6 +518,7 @@ __device__ __forceinline__ float from_fix40(unsigned long long v) { return (floa
 // ------------------------------------------------------------------------------------------------
 // Gradient on demand: SIFTGradient.metal:15-39 (atan2(tx, ty) -- argument order as in the
 // reference -- and |grad| of central differences, mirror edges); outside the image -> (0, 0).
+template <bool FAST_SQRT = false>
 __device__ __forceinline__ void gradient_at(const float *g, int w, int h, int gx, int gy, float &theta, float &mag) {
     if (gx < 0 || gy < 0 || gx >= w || gy >= h) { theta = 0.0f; mag = 0.0f; return; }
     float tx, ty;
@@ -507,7 +534,7 @@ __device__ __forceinline__ void gradient_at(const float *g, int w, int h, int gx
         ty = (rd(gx, py) - rd(gx, my)) * 0.5f;
     }
     theta = atan2f(tx, ty);
-    mag = sqrtf(tx * tx + ty * ty);
+    mag = FAST_SQRT ? __builtin_amdgcn_sqrtf(tx * tx + ty * ty) : sqrtf(tx * tx + ty * ty);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -549,16 +576,19 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
             const int y = (int)roundf((float)absoluteY / delta);
             const float sigma = kp.sigma / delta;
             const float exponentDenominator = 2.0f * lambda * lambda;
+            // per keypoint: the two reciprocals the sample loop multiplies by (the reference divides per sample; float
+            // note at descriptor_kernel: the weight of a sample moves by 1-2 ulp, the bin it goes to does not depend on it)
+            const float inv_sigma = 1.0f / sigma, neg_inv_den = -1.0f / exponentDenominator;
             const int r = (int)ceilf(3.0f * lambda * sigma);
             const int side = 2 * r + 1, total = side * side;
             for (int idx = lane; idx < total; idx += 64) {
                 const int jj = idx / side, ii = idx - jj * side;
                 const int j = jj - r, i = ii - r;
-                const float u = (float)i / sigma, v = (float)j / sigma;
+                const float u = (float)i * inv_sigma, v = (float)j * inv_sigma;
                 const float r2 = u * u + v * v;
-                const float wgt = expf(-r2 / exponentDenominator);
+                const float wgt = __expf(r2 * neg_inv_den);
                 float orientation, magnitude;
-                gradient_at(g, w, h, x + i, y + j, orientation, magnitude);
+                gradient_at<true>(g, w, h, x + i, y + j, orientation, magnitude);
                 const float t = orientation / (2.0f * SIFTMI_PI_F);
                 int bin = (int)roundf(t * (float)ORI_BINS);
                 if (bin < 0) bin += ORI_BINS;
@@ -642,13 +672,13 @@ __global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P,
 // scattered trilinearly into a 4x4x8 LDS histogram (u64 fixed point, see to_fix40); the two L2
 // normalisations are wave reductions.  Samples whose truncated coordinate leaves the image contribute nothing (the
 // reference's behaviour there is undefined).
-__device__ __forceinline__ void add_value(unsigned long long *patch, int x, int y, int b, float value) {   // :59-79
-    if (x < 0 || x >= 4 || y < 0 || y >= 4) return;
-    if (b < 0) b += 8;
-    if (b >= 8) b -= 8;
-    atomicAdd(&patch[(y * 4 * 8) + (x * 8) + b], to_fix40(value));
-}
-
+// Float note.  Per sample the reference divides by histogramWidth twice, calls exp and sqrt.  Metal compiles those with
+// fast math (reciprocal multiply, native exp / sqrt, ~1-2 ulp); here: one IEEE reciprocal per descriptor and a multiply
+// per sample, v_exp_f32 (__expf) and v_sqrt_f32 -- 1-2 ulp on quantities that only weight a sample, against a stated
+// descriptor tolerance of 1e-4 (L2).  Measured against the oracle (IEEE division, glibc expf / sqrtf) on 17.6 k dense
+// descriptors: max L2 5.1e-7 with either form, 9 instead of 5 of 2.25 M quantised bins differ by 1
+// (tools/desc_margin.py); the sample loop is VALU-bound and this removes ~50 of its ~330 instructions.  atan2f stays
+// the library's: the orientation bin it feeds is interpolated, and the orientation stage bins to the nearest integer.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -703,6 +733,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
         const float sigma = 1.6f;
         const float sc = sigma * powf(2.0f, interval / intervals);
         const float histogramWidth = 3.0f * sc;
+        const float inv_hw = 1.0f / histogramWidth;
         const int radius = (int)(histogramWidth * sqrtf(2.0f) * ((float)d + 1.0f) * 0.5f + 0.5f);
 
         if (COOP) {
@@ -778,8 +809,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
                 const int ii = idx / side;
                 i = ii - radius; j = idx - ii * side - radius;
             }
-            const float rx = ((float)j * cosT - (float)i * sinT) / histogramWidth;
-            const float ry = ((float)j * sinT + (float)i * cosT) / histogramWidth;
+            const float rx = ((float)j * cosT - (float)i * sinT) * inv_hw;         // "/ histogramWidth" in the reference: see the float note above
+            const float ry = ((float)j * sinT + (float)i * cosT) * inv_hw;
             const float bx = rx + (float)(d / 2) - 0.5f;
             const float by = ry + (float)(d / 2) - 0.5f;
             // every trilinear corner of this sample lies outside the 4x4 grid (addValue :66-68 drops
@@ -787,30 +818,36 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
             if (bx <= -1.0f || bx >= 4.0f || by <= -1.0f || by >= 4.0f) continue;
             const float fx = truncf(px + (float)j), fy = truncf(py + (float)i);   // ushort2(px + j, py + i)
             float gth = 0.0f, gm = 0.0f;
-            if (fx >= 0.0f && fy >= 0.0f && fx < (float)w && fy < (float)h) gradient_at(g, w, h, (int)fx, (int)fy, gth, gm);
+            if (fx >= 0.0f && fy >= 0.0f && fx < (float)w && fy < (float)h) gradient_at<true>(g, w, h, (int)fx, (int)fy, gth, gm);
             float orientation = gth - theta;
             while (orientation < 0.0f) orientation += tau;
             while (orientation >= tau) orientation -= tau;
             const float bin = orientation * binsPerRadian;
             const float exponentNumerator = rx * rx + ry * ry;
-            const float wgt = expf(-exponentNumerator / exponentDenominator);
+            const float wgt = __expf(-exponentNumerator / exponentDenominator);
             const float value = gm * wgt;
-            {   // addFeature :82-117
+            {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
+                // and bin wrap (:59-79); here one test per cell corner, the two orientation bins wrapped once (bin lies in
+                // [0, 8]: floor / ceil can reach 8, never go negative).  Same products in the same order.
                 const float flx = floorf(bx), fly = floorf(by), flb = floorf(bin);
                 const int cax = (int)flx, cay = (int)fly;
                 const int cbx = (int)ceilf(bx), ccy = (int)ceilf(by);
-                const int ba = (int)flb, bb = (int)ceilf(bin);
+                int ba = (int)flb, bb = (int)ceilf(bin);
+                if (ba >= 8) ba -= 8;
+                if (bb >= 8) bb -= 8;
                 const float iMax = bx - flx, iMin = 1.0f - iMax;
                 const float jMax = by - fly, jMin = 1.0f - jMax;
                 const float bMax = bin - flb, bMin = 1.0f - bMax;
-                add_value(patch, cax, cay, ba, (iMin * jMin * bMin) * value);
-                add_value(patch, cax, cay, bb, (iMin * jMin * bMax) * value);
-                add_value(patch, cbx, cay, ba, (iMax * jMin * bMin) * value);
-                add_value(patch, cbx, cay, bb, (iMax * jMin * bMax) * value);
-                add_value(patch, cbx, ccy, ba, (iMax * jMax * bMin) * value);
-                add_value(patch, cbx, ccy, bb, (iMax * jMax * bMax) * value);
-                add_value(patch, cax, ccy, ba, (iMin * jMax * bMin) * value);
-                add_value(patch, cax, ccy, bb, (iMin * jMax * bMax) * value);
+                const bool xa = (unsigned)cax < 4u, xb = (unsigned)cbx < 4u, ya = (unsigned)cay < 4u, yb = (unsigned)ccy < 4u;
+                unsigned long long *pa = patch + ba, *pb = patch + bb;
+                if (xa && ya) { const float wxy = iMin * jMin; const int c = cay * 32 + cax * 8;
+                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
+                if (xb && ya) { const float wxy = iMax * jMin; const int c = cay * 32 + cbx * 8;
+                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
+                if (xb && yb) { const float wxy = iMax * jMax; const int c = ccy * 32 + cbx * 8;
+                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
+                if (xa && yb) { const float wxy = iMin * jMax; const int c = ccy * 32 + cax * 8;
+                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
             }
         }
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
