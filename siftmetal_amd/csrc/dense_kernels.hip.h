@@ -152,6 +152,30 @@ struct VTaps {
     }
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) volatile f32x2 lds_cv_f32x2;
+
+// Mirror extension without a branch (both blur kernels' row loads).  For w % 4 == 0 a float4 at columns gx ... gx+3
+// (gx % 4 == 0) lies wholly inside or wholly outside the image, and outside it is the float4 at -gx - 4 (left) or
+// 2w - 4 - gx (right) with its elements reversed (one reflection; Common.hpp:15-22).  The clamp only matters for far
+// halo columns of a partial tile that no output depends on: it keeps their address inside the row.
+__device__ __forceinline__ f32x4 load_quad_mirrored(const float *rowp, int gx, int w) {
+    const bool mir = gx < 0 || gx >= w;
+    const int g2 = min(max(gx < 0 ? -gx - 4 : (gx >= w ? 2 * w - 4 - gx : gx), 0), w - 4);
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + g2);
+    f32x4 r;
+    r.x = mir ? v.w : v.x; r.y = mir ? v.z : v.y; r.z = mir ? v.y : v.z; r.w = mir ? v.x : v.w;
+    return r;
+}
+__device__ __forceinline__ f32x2 load_pair_mirrored(const float *rowp, int gx, int w) {      // gx even, w even
+    const bool mir = gx < 0 || gx >= w;
+    const int g2 = min(max(gx < 0 ? -gx - 2 : (gx >= w ? 2 * w - 2 - gx : gx), 0), w - 2);
+    const f32x2 v = *reinterpret_cast<const f32x2 *>(rowp + g2);
+    f32x2 r;
+    r.x = mir ? v.y : v.x; r.y = mir ? v.x : v.y;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // One Gaussian layer: dst = blur_R(src), separable, mirror extension.  SEED = true: src is ignored and
 // the input is seed_sample() of the frame's pixels.  Tile height, workgroup size, vertical register
@@ -159,9 +183,14 @@ struct VTaps {
 // tools/ubench/blur_variants.hip can time variants; BlurShip below is the shipping choice.
 template <int R, int TH_, int NTHR_, int HO_, int RB_>
 struct Blur2Geom {
-    static constexpr int RP = (R + 3) & ~3;
+    // staged halo of 8 or 16 columns per side: a staged row is then a whole number of float4 (+ one float2) for each of
+    // the 8 lanes that load it (see the staging code)
+    static constexpr int RP = R <= 8 ? 8 : 16;
     static constexpr int TW = 128, TH = TH_, NTHR = NTHR_, HO = HO_, RB = RB_;
     static constexpr int LW = TW + 2 * RP, LH = TH + 2 * R, NT = 2 * R + 1;
+    static constexpr int NPF4 = LW / 32, REM = (LW - 32 * NPF4) / 8;          // per lane and staged row: float4s + floats left over
+    static constexpr int NBATCH = (LH * 8 + NTHR - 1) / NTHR;                 // row batches of NTHR / 8 rows
+    static_assert((REM == 0 || REM == 2) && (NPF4 * 4 + REM) * 8 == LW, "row decomposition");
     static constexpr int V_ITEMS = (TW / 4) * (TH / RB);
     static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
     // seed variant: luma of the input pixels under the staged 2x window, computed once per workgroup
@@ -199,12 +228,30 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
     const unsigned char *px = SEED ? seed.pixels + (size_t)frame * seed.frame_stride : nullptr;
 
     const bool interior = (x0 - G::RP >= 0) && (x0 + G::TW + G::RP <= w) && (y0 - R >= 0) && (y0 + G::TH + R <= h);
-    if (!SEED && interior && (w & 3) == 0) {
-        constexpr int V = G::LW / 4;
-        for (int idx = tid; idx < G::LH * V; idx += NTHR) {
-            const int ly = idx / V, lv = idx - ly * V;
-            const float4 v = *reinterpret_cast<const float4 *>(in + (size_t)(y0 - R + ly) * w + (x0 - G::RP) + 4 * lv);
-            *reinterpret_cast<float4 *>(lds + ly * G::LW + 4 * lv) = v;
+    // Row staging, fast form: 8 lanes per row (float4 columns q + 8 j and the float2 left over), NTHR / 8 rows per batch,
+    // EVERY load of every batch issued before the first LDS store -- one memory latency per tile.  (Round 1 staged with a
+    // load -> wait -> store loop: 9 latencies for an interior tile, 36 for a border tile with its per-element mirror
+    // arithmetic, which put a floor of ~17 us under every small-octave launch.)  Mirrored rows and columns cost no branch
+    // (symm per row, load_quad_mirrored); needs w % 4 == 0 and an image of at least 16 x 16 so that one reflection
+    // reaches every input an output depends on.
+    if (!SEED && (w & 3) == 0 && w >= 16 && h >= 16) {
+        const int prow = tid / 8, pq = tid & 7;
+        f32x4 buf[G::NBATCH][G::NPF4];
+        f32x2 rem[G::NBATCH];
+#pragma unroll
+        for (int b = 0; b < G::NBATCH; b++) {
+            const int ly = min(b * (NTHR / 8) + prow, G::LH - 1);
+            const float *rowp = in + (size_t)min(max(symm(y0 - R + ly, h), 0), h - 1) * w;
+#pragma unroll
+            for (int j = 0; j < G::NPF4; j++) buf[b][j] = load_quad_mirrored(rowp, x0 - G::RP + 4 * pq + 32 * j, w);
+            if (G::REM) rem[b] = load_pair_mirrored(rowp, x0 - G::RP + 32 * G::NPF4 + 2 * pq, w);
+        }
+#pragma unroll
+        for (int b = 0; b < G::NBATCH; b++) {
+            float *rowp = lds + min(b * (NTHR / 8) + prow, G::LH - 1) * G::LW;      // lanes past the last row repeat it
+#pragma unroll
+            for (int j = 0; j < G::NPF4; j++) *reinterpret_cast<f32x4 *>(rowp + 4 * pq + 32 * j) = buf[b][j];
+            if (G::REM) *reinterpret_cast<f32x2 *>(rowp + 32 * G::NPF4 + 2 * pq) = rem[b];
         }
     } else if (SEED) {
         // luma (ConvertSRGBToGrayscale.metal) of every input pixel the staged window can touch, once,
@@ -212,9 +259,22 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
         // luma is reused by >= 4 upscaled samples, and the byte->float divisions are the expensive part.
         float *lum = lds + G::LH * G::LW;
         const int ix0 = ((x0 - G::RP) >> 1) - 1, iy0 = ((y0 - R) >> 1) - 1;
-        for (int idx = tid; idx < G::LHI * G::LWI; idx += NTHR) {
-            const int ly = idx / G::LWI, lx = idx - ly * G::LWI;
-            lum[idx] = luma_at(px, seed, ix0 + lx, iy0 + ly);             // 0 outside the image
+        {   // all pixel loads first (clamped coordinates, so none is conditional), then the lumas: one memory latency
+            constexpr int NL = (G::LHI * G::LWI + NTHR - 1) / NTHR;
+            unsigned raw[NL];
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const int idx = min(tid + k * NTHR, G::LHI * G::LWI - 1);
+                const int ly = idx / G::LWI, lx = idx - ly * G::LWI;
+                raw[k] = raw_pixel(seed.format, px, seed, min(max(ix0 + lx, 0), seed.in_w - 1), min(max(iy0 + ly, 0), seed.in_h - 1));
+            }
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const int idx = min(tid + k * NTHR, G::LHI * G::LWI - 1);
+                const int ly = idx / G::LWI, lx = idx - ly * G::LWI;
+                const int x = ix0 + lx, y = iy0 + ly;
+                lum[idx] = (x < 0 || y < 0 || x >= seed.in_w || y >= seed.in_h) ? 0.0f : luma_of(seed.format, raw[k]);   // 0 outside the image
+            }
         }
         __syncthreads();
         const int wi = seed.in_w, hi = seed.in_h;
@@ -280,18 +340,19 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
     for (int item = tid; item < G::LH * (G::TW / 4); item += NTHR) {
         const int row = item >> 5, c4 = (item & 31) * 4;
         float *rowp = lds + row * G::LW;
-        float v[4 + 2 * G::RP];
+        constexpr int M0 = (G::RP - R) / 4, M1 = (G::RP + R + 3) / 4 + 1;      // float4 of the row segment that hold the taps' operands
+        float v[4 * (M1 - M0)];
         const lds_cv_f32x4 *rp4 = (const lds_cv_f32x4 *)(rowp + c4);
 #pragma unroll
-        for (int m = 0; m < (4 + 2 * G::RP) / 4; m++) {
+        for (int m = M0; m < M1; m++) {
             const f32x4 t = rp4[m];
-            v[4 * m + 0] = t.x; v[4 * m + 1] = t.y; v[4 * m + 2] = t.z; v[4 * m + 3] = t.w;
+            v[4 * (m - M0) + 0] = t.x; v[4 * (m - M0) + 1] = t.y; v[4 * (m - M0) + 2] = t.z; v[4 * (m - M0) + 3] = t.w;
         }
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < G::NT; i++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(G::RP - R) + k + i], acc[k]);
+            for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(G::RP - R - 4 * M0) + k + i], acc[k]);
         }
         *reinterpret_cast<float4 *>(rowp + G::RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
@@ -626,9 +687,6 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
     __device__ __forceinline__ float operator()(int i) const { return w[i <= R ? i : 2 * R - i]; }
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) volatile f32x2 lds_cv_f32x2;
-
 // max of a non-negative value over the 16 lanes of a DPP row, valid in the row's lane 15 (row_shr 1, 2, 4, 8: lane i ends
 // with the max over lanes i-15 ... i; lanes without a source keep their own value).  Pure VALU: __shfl_xor goes through
 // the LDS crossbar (ds_swizzle / ds_bpermute) and this runs once per horizontal-pass item.
@@ -698,9 +756,8 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
     };
     // Row loads of the fast path.  8 lanes per row: lane q of a row takes the float4 columns q + 8 j (j < NPF4) and, when
     // the row length leaves a remainder, the float2 at float 32 NPF4 + 2 q -- one address register per side and immediate
-    // offsets.  The mirror extension costs no branch: a row index is mirrored once per lane (symm), and a float4 that lies
-    // outside the image on the left / right is the float4 at -gx - 4 / 2w - 4 - gx with its elements reversed (w % 4 == 0,
-    // single reflection), so border strips and border rows issue exactly the loads interior ones do.
+    // offsets.  The mirror extension costs no branch: a row index is mirrored once per lane (symm) and columns by
+    // load_quad_mirrored, so border strips and border rows issue exactly the loads interior ones do.
     // Needs: w a multiple of 4, a whole strip, and an image large enough for single reflections.
     const bool colfast = (w & 3) == 0 && w >= 64 && h >= 64 && x0 + G::TW <= w;
     const int pf_row = tid >> 3, pf_q = tid & 7;
@@ -708,19 +765,8 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         const int sy = symm(y_first + min(pf_row, nrows - 1), h);
         const float *rowp = in + (size_t)sy * w;
 #pragma unroll
-        for (int j = 0; j < G::NPF4; j++) {
-            const int gx = x0 - RP + 4 * pf_q + 32 * j;
-            const bool mir = gx < 0 || gx >= w;
-            const int g2 = gx < 0 ? -gx - 4 : (gx >= w ? 2 * w - 4 - gx : gx);
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + g2);
-            buf[j].x = mir ? v.w : v.x; buf[j].y = mir ? v.z : v.y; buf[j].z = mir ? v.y : v.z; buf[j].w = mir ? v.x : v.w;
-        }
-        if (G::REM) {                                        // the last 16 halo columns, right of the strip
-            const int gx = x0 - RP + 32 * G::NPF4 + 2 * pf_q;
-            const bool mir = gx >= w;
-            const f32x2 v = *reinterpret_cast<const f32x2 *>(rowp + (mir ? 2 * w - 2 - gx : gx));
-            rem.x = mir ? v.y : v.x; rem.y = mir ? v.x : v.y;
-        }
+        for (int j = 0; j < G::NPF4; j++) buf[j] = load_quad_mirrored(rowp, x0 - RP + 4 * pf_q + 32 * j, w);
+        if (G::REM) rem = load_pair_mirrored(rowp, x0 - RP + 32 * G::NPF4 + 2 * pf_q, w);   // the last 16 halo columns, right of the strip
     };
     auto store_rows = [&](int u_first, int nrows, const f32x4 (&buf)[G::NPF4], const f32x2 &rem) {   // -> ring rows u_first + ...
         float *rowp = lds + ((u_first + min(pf_row, nrows - 1) + NR) & (NR - 1)) * LW;     // lanes past nrows repeat the last row

@@ -1,57 +1,70 @@
 #!/bin/bash
 # Round profile (run on the GPU box through gpurun): kernel-trace stats of the bench command and
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) of the Gaussian-layer blur kernel.
-# usage: bash tools/profile_round.sh r01
-TAG=${1:-r01}
+# usage: bash tools/profile_round.sh r02
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 rm -rf $OUT; mkdir -p $OUT
 # 1. per-kernel time of exactly the bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-# 2. HBM bytes of the blur kernel: octave 0, all five layers, 8 frames per launch
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/tools/prof_blur.py 0 0 5 8 > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/tools/prof_blur.py 0 0 5 8 > $OUT/write.log 2>&1
+# 2. HBM bytes of the blur kernel: the five octave-0 layer launches of the pipeline itself (8 frames per launch, one call),
+#    plus the calibration copy with the same access shapes and a known byte count (tools/ubench/pmc_calib.hip)
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/tools/prof_pipeline.py 8 8 2 > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $OUT/calib_$C -- $R/tools/ubench/pmc_calib 3840 2160 8 5 > $OUT/calib_$C.log 2>&1
+done
 python3 - <<PY
-import csv, glob, json, collections, os
-out = "$OUT"
+import csv, glob, json, collections, re
+out, tag = "$OUT", "$TAG"
 # --- kernel stats
 stats = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
-rows = []
-if stats:
-    rows = list(csv.DictReader(open(stats[0])))
-with open(out + "/kernel_stats_$TAG.csv", "w") as f:
+rows = list(csv.DictReader(open(stats[0]))) if stats else []
+with open(out + "/rocprof_kernel_stats_%s.csv" % tag, "w") as f:
     if rows:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-for r in rows[:14]:
-    print("%-70s calls %6s total_ns %12s avg_ns %10s pct %s" % (r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
-# --- traffic: dispatches of the full-size octave-0 launches = those with the largest grid
-def collect(d, name):
+for r in rows[:16]:
+    print("%-74s calls %6s total_ns %12s avg_ns %10s pct %s" % (r.get("Name", "")[:74], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+
+def collect(d, counter, want):
     vals = collections.defaultdict(list)
     for f in glob.glob(out + "/" + d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != name: continue
-            k = r["Kernel_Name"]
-            if "blur_march_kernel" not in k: continue        # the octave-0 launches of tools/prof_blur.py use the marching kernel
-            vals[(k.split("(")[0][-90:], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] != counter or want not in r["Kernel_Name"]: continue
+            vals[(r["Kernel_Name"].split("(")[0][-100:], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return vals
-fetch, write = collect("fetch", "FETCH_SIZE"), collect("write", "WRITE_SIZE")
-res = []
 W, H, NF = 3840, 2160, 8
 alg = 8 * W * H * NF
+# calibration: known 4 B/px read + 4 B/px written with the ring kernel's access shapes
+cal = {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    v = collect("calib_" + C, C, "calib_copy_kernel")
+    xs = sorted(sum(v.values(), []))
+    cal[C] = (4.0 * W * H * NF) / (xs[len(xs) // 2] * 1024.0) if xs else None
+print("calibration (known bytes / counter KiB x 1024):", cal)
+fetch, write = collect("pmc_FETCH_SIZE", "FETCH_SIZE", "blur_ring_kernel"), collect("pmc_WRITE_SIZE", "WRITE_SIZE", "blur_ring_kernel")
+res = []
 for key in sorted(fetch, key=lambda k: -k[1]):
     kname, grid = key
-    if "true" in kname.split("blur2_kernel")[-1].split(",")[5:6]: pass
-    f = sorted(fetch[key]); wv = sorted(write.get(key, [0]))
+    f, wv = sorted(fetch[key]), sorted(write.get(key, [0.0]))
     fm, wm = f[len(f) // 2], wv[len(wv) // 2]
-    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
-    # streaming reads (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE is exact for 16-B stores
-    hbm = 2 * fm * 1024 + wm * 1024
-    res.append({"kernel": kname, "grid": grid, "launches_sampled": len(f), "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm,
-                "hbm_bytes_per_launch_corrected": hbm})
-res = [r for r in res if r["grid"] == max(x["grid"] for x in res)]     # octave-0 launches only
-json.dump({"workload": "octave 0 (3840x2160), 8 frames per launch", "algorithmic_bytes_per_launch": alg, "kernels": res,
-           "correction": "hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"},
-          open(out + "/blur_hbm_traffic_$TAG.json", "w"), indent=1)
-for r in res: print(r["kernel"][-50:], r["grid"], "traffic/algorithmic = %.2f" % (r["hbm_bytes_per_launch_corrected"] / alg))
+    m = re.search(r"blur_ring_kernel<(\d+), \d+, \d+, (true|false), (true|false), \d+, (-?\d+)>", kname)
+    hbm = (cal["FETCH_SIZE"] or 2.0) * fm * 1024 + (cal["WRITE_SIZE"] or 1.0) * wm * 1024
+    res.append({"kernel": kname.replace("void siftmi::", ""), "grid": grid, "launches_sampled": len(f), "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm,
+                "hbm_bytes_per_launch_corrected": hbm, "radius": int(m.group(1)) if m else None, "seed": bool(m and int(m.group(4)) >= 0),
+                "decimating": bool(m and m.group(2) == "true"), "activity_flags": bool(m and m.group(3) == "true")})
+top = max((x["grid"] for x in res if not x["seed"]), default=0)
+for x in res:
+    x["pipeline_layer"] = (not x["seed"]) and x["grid"] == top          # the five octave-0 layer launches
+json.dump({"workload": "octave 0 (3840x2160) of tools/prof_pipeline.py, 8 frames per launch", "algorithmic_bytes_per_launch": alg, "kernels": res,
+           "calibration": {"kernel": "tools/ubench/pmc_calib.hip (same load / store shapes, 4 B read + 4 B written per pixel)",
+                           "bytes_per_FETCH_SIZE_KiB": None if cal["FETCH_SIZE"] is None else cal["FETCH_SIZE"] * 1024,
+                           "bytes_per_WRITE_SIZE_KiB": None if cal["WRITE_SIZE"] is None else cal["WRITE_SIZE"] * 1024},
+           "correction": "hbm = cal_fetch * FETCH_SIZE * 1024 + cal_write * WRITE_SIZE * 1024 with the factors measured by the calibration copy "
+                         "(MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16-B-per-lane read -> ~2; WRITE_SIZE is "
+                         "specified exact for 16-B stores only, the ring kernel stores 8 B per lane)"},
+          open(out + "/blur_hbm_traffic_%s.json" % tag, "w"), indent=1)
+for x in res:
+    if x["pipeline_layer"]: print("R=%2d dec=%d act=%d grid %d traffic/algorithmic = %.3f" % (x["radius"], x["decimating"], x["activity_flags"], x["grid"], x["hbm_bytes_per_launch_corrected"] / alg))
 PY
