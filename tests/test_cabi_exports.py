@@ -101,3 +101,22 @@ def test_swift_stub_files_match_integration_md():
     assert used and all(re.search(r"\b%s\s*\(" % u, hdr) for u in used - {"siftmi_config", "siftmi_keypoint", "siftmi_descriptor"}), used
     man = open(os.path.join(ROOT, "swift", "Package.swift")).read()
     assert '.systemLibrary(name: "CSiftmi"' in man and '.linkedLibrary("siftmi")' in man
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """bench.py --gpus N spawns its own ranks; with fewer than N devices it must fail loudly before any GPU call
+    (`--gpus 8` used to run ONE rank silently and print n_gpus 1)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("more devices than the test asks for")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"--gpus 64" in p.stderr and not p.stdout.strip()
+    # a torchrun environment whose WORLD_SIZE disagrees with --gpus is refused as well
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env2, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"WORLD_SIZE is 2" in p.stderr

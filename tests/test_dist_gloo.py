@@ -101,3 +101,56 @@ def test_gather_results_world2_gloo():
     assert outs[0]["own"][2] == [0, 2, 4] and outs[1]["own"][2] == [1, 3]
     tot = outs[0]["totals"]
     assert tot[:, 1].min() > 10
+
+
+def _exchange_worker(rank, world, port, q):
+    """ResultExchange over three steps: payload gathers of step k sized from step k-1; a step whose counts outgrow the
+    previous step's size (plus headroom) is reported as incomplete one step late."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from siftmetal_amd import dist as smdist
+        cap = 4096
+        ex = smdist.ResultExchange(cap, cap, headroom=1.25, quantum=64)
+        rng = np.random.default_rng(100 + rank)
+        got = []
+        for step, (nk, nd) in enumerate([(100 + 10 * rank, 120 + 7 * rank), (110 + 3 * rank, 90), (900 + rank, 1000)]):
+            kp = torch.from_numpy(rng.integers(0, 256, cap * smdist.KP_BYTES, dtype=np.uint8))
+            ds = torch.from_numpy(rng.integers(0, 256, cap * smdist.DESC_BYTES, dtype=np.uint8))
+            counts = torch.full((2, 3, 2), step + rank, dtype=torch.int32)
+            totals = torch.tensor([nk, nd, 0, 0], dtype=torch.int32)
+            g = ex.gather(kp, ds, counts, totals)
+            got.append({"sent": g["records_per_rank"], "totals": g["totals_device"].numpy().copy(),
+                        "own_kp": kp[:nk * smdist.KP_BYTES].numpy().tobytes(),
+                        "rows_kp": [g["keypoints"][r, :min(int(g["totals_device"][r, 0]), g["records_per_rank"][0]) * smdist.KP_BYTES].numpy().tobytes()
+                                    for r in range(world)]})
+        incomplete, overflow = ex.finish()
+        q.put({"rank": rank, "steps": got, "incomplete": incomplete, "overflow": overflow})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_result_exchange_world2_gloo_sizes_from_previous_step():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for o in outs:
+        # step 0 sizes from its own counts (first step), step 1 from step 0, step 2 from step 1 -> too small for 900 / 1000 records
+        assert o["incomplete"] == [2] and o["overflow"] == []
+        assert o["steps"][0]["sent"][0] >= 110 and o["steps"][1]["sent"][0] >= 113
+        assert o["steps"][2]["sent"][0] < 900
+        assert np.array_equal(o["steps"][1]["totals"][:, 0], [110, 113])
+    for step in range(2):                      # complete steps: every rank holds every rank's exact keypoint bytes
+        for viewer in outs:
+            for r in range(world):
+                assert viewer["steps"][step]["rows_kp"][r] == outs[r]["steps"][step]["own_kp"]

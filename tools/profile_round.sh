@@ -8,12 +8,12 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/profile_$TAG
 rm -rf $OUT; mkdir -p $OUT
 # 1. per-kernel time of exactly the bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 # 2. HBM bytes of the blur kernel: the five octave-0 layer launches of the pipeline itself (8 frames per launch, one call),
 #    plus the calibration copy with the same access shapes and a known byte count (tools/ubench/pmc_calib.hip)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/tools/prof_pipeline.py 8 8 2 > $OUT/pmc_$C.log 2>&1
-  rocprofv3 --pmc $C --output-format csv -d $OUT/calib_$C -- $R/tools/ubench/pmc_calib 3840 2160 8 5 > $OUT/calib_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $OUT/calib_$C -- $R/tools/ubench/pmc_calib 3840 2176 8 5 > $OUT/calib_$C.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections, re
@@ -41,7 +41,7 @@ cal = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     v = collect("calib_" + C, C, "calib_copy_kernel")
     xs = sorted(sum(v.values(), []))
-    cal[C] = (4.0 * W * H * NF) / (xs[len(xs) // 2] * 1024.0) if xs else None
+    cal[C] = (4.0 * 3840 * 2176 * 8) / (xs[len(xs) // 2] * 1024.0) if xs else None    # the calibration image is 3840 x 2176 (whole 32-row steps)
 print("calibration (known bytes / counter KiB x 1024):", cal)
 fetch, write = collect("pmc_FETCH_SIZE", "FETCH_SIZE", "blur_ring_kernel"), collect("pmc_WRITE_SIZE", "WRITE_SIZE", "blur_ring_kernel")
 res = []
