@@ -713,7 +713,7 @@ __device__ __forceinline__ float row16_max_to_lane15(float e) {
 // float rows of a layer blur (6 dwords per lane instead of 18 floats), turned into luma ONCE per input pixel into a tile
 // that borrows the dead rows of the current ring half, and expanded from there into the ring rows (an even output row /
 // column is a luma row / column exactly, an odd one the 0.5 / 0.5 blend, in the reference's expression order).
-template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool ST16 = false>
+template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1>
 __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                              int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
@@ -947,29 +947,12 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             unsigned act_mask = 0;                          // wave-uniform: bit rr / RB + rr = cell 0 / 1 of output row rr is active
             stamp(3);
             const int gx = x0 + 2 * lane;
-            if (FAST && ST16 && !(DBG & 2)) {
-                // 16-byte stores: lanes 2m / 2m+1 hold columns 4m, 4m+1 / 4m+2, 4m+3 of the same RB rows; they swap halves so that
-                // the even lane stores the even row of a row pair and the odd lane the odd row, each as one float4
-                const bool odd = lane & 1;
-                float *o = out + (size_t)(y0 + wv * RB + (odd ? 1 : 0)) * w + x0 + 4 * (lane >> 1);
-#pragma unroll
-                for (int p = 0; p < RB / 2; p++) {
-                    const f32x2 mine = odd ? acc[2 * p + 1] : acc[2 * p], send = odd ? acc[2 * p] : acc[2 * p + 1];
-                    f32x2 recv;
-                    recv.x = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send.x), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
-                    recv.y = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send.y), 0xB1, 0xf, 0xf, true));
-                    f32x4 v;
-                    v.x = odd ? recv.x : mine.x; v.y = odd ? recv.y : mine.y; v.z = odd ? mine.x : recv.x; v.w = odd ? mine.y : recv.y;
-                    *reinterpret_cast<f32x4 *>(o + (size_t)(2 * p) * w) = v;
-                }
-            }
 #pragma unroll
             for (int rr = 0; rr < ((DBG & 2) ? 0 : RB); rr++) {
                 const int gy = y0 + wv * RB + rr;            // wave-uniform
                 if (!FAST && gy >= h) continue;
                 float *o = out + (size_t)gy * w + gx;
-                if (FAST && ST16) {
-                } else if (FAST || (gx + 1 < w && (w & 1) == 0)) {
+                if (FAST || (gx + 1 < w && (w & 1) == 0)) {
                     *reinterpret_cast<f32x2 *>(o) = acc[rr];
                 } else {
                     if (gx + 0 < w) o[0] = acc[rr].x;
