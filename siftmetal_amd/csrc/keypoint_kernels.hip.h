@@ -110,20 +110,39 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
     const bool active = (lane >= 1 && lane <= 62 && x >= 1 && x <= w - 2);
     const int xc = min(x, w - 1);                          // clamped column so out-of-image lanes load safely
 
-    // window rows as separate arrays so that rotating them is a renaming (3x unrolled loop), not 45 moves
-    float ra[ND][3], rb[ND][3], rc[ND][3];
-    // loads are issued one row ahead of their use (raw Gaussian values wait in `pend` while the previous
-    // row is tested), which doubles the bytes in flight per wave of this bandwidth-bound kernel
-    float pend[ND + 1];
-    auto issue = [&](int y) {
-        const float *p = g0 + (size_t)min(y, h - 1) * w + xc;
+    // The walk.  `need` (wave-uniform, bit i = row ya - 1 + i) marks the rows whose values are read, `centre` the rows that
+    // are tested.  The needed rows are visited in order, k = 0, 1, 2, ...; the k-th one lives in window slot k % 3 and its
+    // raw Gaussian values arrive in load buffer k % 3, both static because the loop is unrolled three times.  A row is
+    // tested when the row below it has arrived; then the three rows of its window are the last three needed rows (need
+    // contains every tested row's neighbours), i.e. slots (k-2) % 3, (k-1) % 3, k % 3.
+    // Loads run THREE needed rows ahead of their use whatever the gaps between needed rows (18 loads = 4.6 KB per wave in
+    // flight).  hipcc cannot count that: with the loads behind wave-uniform branches its merged s_waitcnt scoreboard waits
+    // for vmcnt(0), and round 1's one-row-ahead form exposed a full memory latency at the start of every cluster of flagged
+    // rows (the flagged scan ran 1.7x faster than the full one while loading 3x less).  So the loads are asm statements
+    // the compiler does not count, issued UNCONDITIONALLY once per visited row (past the last needed row they re-read
+    // it), which makes the wait a constant: when row k is consumed exactly the loads of rows k+1 and k+2 are younger,
+    // s_waitcnt vmcnt(2 (ND + 1)).  (Any other vector-memory instruction issued in between only makes that wait longer.)
+    float win0[ND][3], win1[ND][3], win2[ND][3];
+    float buf0[ND + 1], buf1[ND + 1], buf2[ND + 1];
+    const float *lbase[ND + 1];
 #pragma unroll
-        for (int l = 0; l <= ND; l++) pend[l] = p[(size_t)l * n];
+    for (int l = 0; l <= ND; l++) lbase[l] = g0 + (size_t)l * n;           // wave-uniform layer bases (SGPR pairs)
+    auto issue = [&](int y, float (&buf)[ND + 1]) {
+        const unsigned voff = (unsigned)((min(y, h - 1) * w + xc) * 4);     // byte offset inside a layer (< 2^31: siftmi_create)
+        asm volatile("s_nop 4" ::: "memory");                               // SGPR bases may be fresh: VMEM reads them (ISA hazard table)
+#pragma unroll
+        for (int l = 0; l <= ND; l++) asm volatile("global_load_dword %0, %1, %2" : "=v"(buf[l]) : "v"(voff), "s"(lbase[l]) : "memory");
     };
-    auto finish = [&](float (&row)[ND][3]) {
+    auto finish = [&](float (&buf)[ND + 1], float (&row)[ND][3]) {
+        // rows k+1 and k+2 are younger: everything older than their 2 (ND + 1) loads has landed
+        if constexpr (ND + 1 == 4) asm volatile("s_waitcnt vmcnt(8)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3])::"memory");
+        if constexpr (ND + 1 == 5) asm volatile("s_waitcnt vmcnt(10)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4])::"memory");
+        if constexpr (ND + 1 == 6) asm volatile("s_waitcnt vmcnt(12)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5])::"memory");
+        if constexpr (ND + 1 == 7) asm volatile("s_waitcnt vmcnt(14)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6])::"memory");
+        if constexpr (ND + 1 == 8) asm volatile("s_waitcnt vmcnt(16)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory");
 #pragma unroll
         for (int l = 0; l < ND; l++) {
-            const float dv = pend[l + 1] - pend[l];
+            const float dv = buf[l + 1] - buf[l];
             row[l][1] = dv;
             row[l][0] = __shfl_up(dv, 1);
             row[l][2] = __shfl_down(dv, 1);
@@ -175,19 +194,12 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
             }
         }
     };
+    // bit i of `centre`: row ya - 1 + i is an output row of this block (SKIP: with an active cell under this wave's columns);
+    // bit i of `need`: that row, or the one above or below it, is such a row, so its values are read.  Wave-uniform.
+    unsigned long long centre;
     if (!SKIP) {
-        issue(ya - 1); finish(ra);
-        issue(ya); finish(rb);
-        issue(ya + 1);
-        for (int y = ya; y < yb; y += 3) {
-            finish(rc); issue(y + 2);
-            test_row(y, ra, rb, rc);
-            if (y + 1 < yb) { finish(ra); issue(y + 3); test_row(y + 1, rb, rc, ra); }
-            if (y + 2 < yb) { finish(rb); issue(y + 4); test_row(y + 2, rc, ra, rb); }
-        }
+        centre = ((1ull << (yb - ya)) - 1ull) << 1;                                       // rows ya ... yb-1 (EH + 2 <= 64)
     } else {
-        // bit i of `centre`: row ya - 1 + i is an output row of this block with an active cell under this wave's columns;
-        // bit i of `need`: that row, or the one above or below it, is such a row, so its values are read.  Wave-uniform.
         const int xw = blockIdx.x * EXT_COLS_PER_BLOCK + wv * EXT_COLS_PER_WAVE;          // column of lane 0
         const int c0 = min((xw + 1) >> 6, ncell - 1), c1 = min((xw + EXT_COLS_PER_WAVE) >> 6, ncell - 1);
         const unsigned char *ap = act + (size_t)frame * act_frame_stride;
@@ -200,30 +212,37 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
                 a = a || q[c0] || q[c1];
             }
         }
-        const unsigned long long centre = __ballot(a);
-        const unsigned long long need = centre | (centre << 1) | (centre >> 1);
-        auto needs = [&](int y) { return ((need >> (y - (ya - 1))) & 1ull) != 0; };        // rows ya-1 ... yb
-        auto tests = [&](int y) { return ((centre >> (y - (ya - 1))) & 1ull) != 0; };
-        if (need != 0ull) {
-            if (needs(ya - 1)) { issue(ya - 1); finish(ra); }
-            if (needs(ya)) { issue(ya); finish(rb); }
-            if (needs(ya + 1)) issue(ya + 1);
-            for (int y = ya; y < yb; y += 3) {
-                if (needs(y + 1)) finish(rc);
-                if (y + 2 <= yb && needs(y + 2)) issue(y + 2);
-                if (tests(y)) test_row(y, ra, rb, rc);
-                if (y + 1 < yb) {
-                    if (needs(y + 2)) finish(ra);
-                    if (y + 3 <= yb && needs(y + 3)) issue(y + 3);
-                    if (tests(y + 1)) test_row(y + 1, rb, rc, ra);
-                }
-                if (y + 2 < yb) {
-                    if (needs(y + 3)) finish(rb);
-                    if (y + 4 <= yb && needs(y + 4)) issue(y + 4);
-                    if (tests(y + 2)) test_row(y + 2, rc, ra, rb);
-                }
+        centre = __ballot(a);
+    }
+    const unsigned long long need = centre | (centre << 1) | (centre >> 1);
+    if (need != 0ull) {
+        unsigned long long todo = need;                     // needed rows not yet requested
+        int last = ya - 1;
+        auto next_row = [&]() {                             // the next needed row; past the end, the last one again
+            if (todo) { last = ya - 1 + __builtin_ctzll(todo); todo &= todo - 1ull; }
+            return last;
+        };
+        const int total = __popcll(need);
+        auto tested = [&](int y) { return y >= ya && ((centre >> (y - (ya - 1))) & 1ull) != 0; };
+        int r0 = next_row(); issue(r0, buf0);
+        int r1 = next_row(); issue(r1, buf1);
+        int r2 = next_row(); issue(r2, buf2);
+        for (int k = 0; k < total; k += 3) {
+            finish(buf0, win0);
+            if (tested(r0 - 1)) test_row(r0 - 1, win1, win2, win0);
+            r0 = next_row(); issue(r0, buf0);
+            if (k + 1 < total) {
+                finish(buf1, win1);
+                if (tested(r1 - 1)) test_row(r1 - 1, win2, win0, win1);
+                r1 = next_row(); issue(r1, buf1);
+            }
+            if (k + 2 < total) {
+                finish(buf2, win2);
+                if (tested(r2 - 1)) test_row(r2 - 1, win0, win1, win2);
+                r2 = next_row(); issue(r2, buf2);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(buf0[0]), "+v"(buf1[0]), "+v"(buf2[0])::"memory");   // the tail re-reads land before the registers die
     }
     __syncthreads();
     const int nloc = min(s_cand, STAGE);

@@ -120,3 +120,22 @@ def test_bench_refuses_more_gpus_than_visible():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env2, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and b"WORLD_SIZE is 2" in p.stderr
+
+
+def test_asm_prefetch_registers_are_not_touched_in_flight():
+    """extrema_kernel issues its row loads as asm statements the compiler does not count (three rows ahead) and waits with a
+    hand-counted vmcnt; hipcc may legally copy or reuse such a destination VGPR before the data lands.  The generated ISA is
+    audited: no compiler instruction names a destination between its load and the wait that retires it."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "siftmetal_amd", "csrc")
+    asm = os.path.join(csrc, "siftmi_api.s")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    if not os.path.exists(asm) or any(os.path.getmtime(f) > os.path.getmtime(asm) for f in srcs):
+        if not os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.skip("no hipcc to regenerate the ISA listing")
+        subprocess.check_call(["make", "-C", csrc, "-s", "asm"])
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), asm], stdout=subprocess.PIPE)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    assert int(re.search(r"audited (\d+) asm loads", out).group(1)) >= 100, out
