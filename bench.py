@@ -134,8 +134,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "32")), help="frames processed in lock-step per launch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "64")), help="frames processed in lock-step per launch")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (cycled to fill the batch)")
+    ap.add_argument("--march-min-blocks", type=int, default=0, help="siftmi_config.blur_march_min_blocks (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip single_frame / host_io / dense")
@@ -186,7 +187,8 @@ def main():
     # every rank gets different frames (rotate) so the gathered descriptors are not copies
     frames_np = np.roll(frames_np, rank, axis=0)
     d_frames = torch.from_numpy(frames_np).to(dev)
-    eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F))
+    tune = {"blur_march_min_blocks": args.march_min_blocks} if args.march_min_blocks > 0 else {}
+    eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
     runner = smstream.FrameStream(eng, F, device=dev, world_size=world)
 
     def barrier():

@@ -758,8 +758,9 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
     // the row length leaves a remainder, the float2 at float 32 NPF4 + 2 q -- one address register per side and immediate
     // offsets.  The mirror extension costs no branch: a row index is mirrored once per lane (symm) and columns by
     // load_quad_mirrored, so border strips and border rows issue exactly the loads interior ones do.
-    // Needs: w a multiple of 4, a whole strip, and an image large enough for single reflections.
-    const bool colfast = (w & 3) == 0 && w >= 64 && h >= 64 && x0 + G::TW <= w;
+    // Needs: w a multiple of 4 and an image large enough for single reflections (a partial last strip is fine: the far halo
+    // columns no output depends on are clamped into the row).
+    const bool colfast = (w & 3) == 0 && w >= 64 && h >= 64;
     const int pf_row = tid >> 3, pf_q = tid & 7;
     auto load_rows = [&](int y_first, int nrows, f32x4 (&buf)[G::NPF4], f32x2 &rem) {     // image rows y_first + (0 ... nrows-1)
         const int sy = symm(y_first + min(pf_row, nrows - 1), h);
@@ -866,7 +867,11 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
     };
     stamp(-1);
     auto body = [&](auto fast_tag, int st) {
-        constexpr bool FAST = decltype(fast_tag)::value;
+        // MODE 2: FAST (prefetched rows, unguarded straight-line stores); 1: prefetched rows, guarded stores (a partial last
+        // strip, a step that runs past the bottom of the image); 0: general (no next step to prefetch for, or an image
+        // the fast loads do not cover)
+        constexpr int MODE = decltype(fast_tag)::value;
+        constexpr bool FAST = MODE >= 1, FULL = MODE == 2;
         const int y0 = ybeg + st * S;                        // first output row of this step
         const bool has_next = FAST || st + 1 < nst;
         lds_barrier();                                       // B1: this step's rows are in LDS
@@ -950,16 +955,16 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
 #pragma unroll
             for (int rr = 0; rr < ((DBG & 2) ? 0 : RB); rr++) {
                 const int gy = y0 + wv * RB + rr;            // wave-uniform
-                if (!FAST && gy >= h) continue;
+                if (!FULL && gy >= h) continue;
                 float *o = out + (size_t)gy * w + gx;
-                if (FAST || (gx + 1 < w && (w & 1) == 0)) {
+                if (FULL || (gx + 1 < w && (w & 1) == 0)) {
                     *reinterpret_cast<f32x2 *>(o) = acc[rr];
                 } else {
                     if (gx + 0 < w) o[0] = acc[rr].x;
                     if (gx + 1 < w) o[1] = acc[rr].y;
                 }
-                if (DEC && ((wv * RB + rr) & 1) == 0 && (FAST || (((gy & 1) == 0) && (gy >> 1) < dec.h2))) {   // y0 is even on the FAST path; gx is even
-                    if (FAST || ((gx >> 1) < dec.w2 && gx < w))
+                if (DEC && (FULL ? ((wv * RB + rr) & 1) == 0 : (((gy & 1) == 0) && (gy >> 1) < dec.h2))) {   // y0 is even on the FAST path; gx is even
+                    if (FULL || ((gx >> 1) < dec.w2 && gx < w))
                         dec.dst[(size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1)] = acc[rr].x;
                 }
                 if (ACT) {                                  // 32 lanes = 64 columns = one cell of this row
@@ -967,8 +972,8 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                     const int slot_c = (st * S + wv * RB + rr - R + NR) & (NR - 1);           // ring row under this output row
                     const float eh = ehm(slot_c, half);
                     const float lim = act.thr * 0.9999f;
-                    const bool f = ((FAST || gx + 0 < w) && fabsf(acc[rr].x - cen[rr].x) + eh > lim) ||
-                                   ((FAST || gx + 1 < w) && fabsf(acc[rr].y - cen[rr].y) + eh > lim);
+                    const bool f = ((FULL || gx + 0 < w) && fabsf(acc[rr].x - cen[rr].x) + eh > lim) ||
+                                   ((FULL || gx + 1 < w) && fabsf(acc[rr].y - cen[rr].y) + eh > lim);
                     const unsigned long long b = __ballot(f);
                     act_mask |= (((unsigned)b != 0u) ? 1u : 0u) << rr | (((unsigned)(b >> 32) != 0u) ? 1u : 0u) << (RB + rr);
                 }
@@ -994,19 +999,23 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         else stage_rows((st + 1) * S, (st + 2) * S);        // general step: mirror per element, straight to LDS
         // keeps LLVM from tail-merging the LDS writes above of the two instantiations: merged, they would be reached from
         // the general body as well and get its conservative s_waitcnt vmcnt(0)
-        if (FAST) asm volatile("; end of a FAST ring step" ::: "memory");
+        if (MODE == 2) asm volatile("; end of a FAST ring step" ::: "memory");
+        else if (MODE == 1) asm volatile("; end of a prefetching ring step with guarded stores" ::: "memory");
         else asm volatile("; end of a general ring step" ::: "memory");
         if (DBG & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(6);
     };
-    // FAST steps: a column-fast strip, a next step to prefetch for, all S output rows inside the image (and, with DEC, an
-    // even first row and a decimated row for every even output row)
-    const bool strip_fast = colfast && (!DEC || ((ybeg & 1) == 0 && (S & 1) == 0));
+    // FAST steps: a whole strip of a column-fast image, a next step to prefetch for, all S output rows inside the image (and,
+    // with DEC, an even first row and a decimated row for every even output row).  A partial last strip and a step that
+    // runs past the bottom still prefetch (MODE 1); only the last step of a chunk and tiny / odd-width images are general.
+    const bool strip_full = colfast && x0 + G::TW <= w && (!DEC || ((ybeg & 1) == 0 && (S & 1) == 0));
     for (int st = 0; st < nst; st++) {
         const int y0 = ybeg + st * S;
-        const bool fast = strip_fast && st + 1 < nst && y0 + S <= h && (!DEC || ((y0 + S - 1) >> 1) < dec.h2);
-        if (fast) body(std::true_type{}, st);
-        else body(std::false_type{}, st);
+        const bool pre = colfast && st + 1 < nst;
+        const bool full = pre && strip_full && y0 + S <= h && (!DEC || ((y0 + S - 1) >> 1) < dec.h2);
+        if (full) body(std::integral_constant<int, 2>{}, st);
+        else if (pre) body(std::integral_constant<int, 1>{}, st);
+        else body(std::integral_constant<int, 0>{}, st);
     }
     if ((DBG & 1) && lane == 0) {
         unsigned long long *d = reinterpret_cast<unsigned long long *>(act.dst) + ((size_t)t * 4 + wv) * 8;

@@ -453,11 +453,11 @@ static void t_collect(siftmi_ctx *c) {
 
 // ------------------------------------------------------------------------------------------------
 // launches
-// Rows per chunk of the marching (ring) blur: a workgroup walks its 128-column strip down one chunk in steps of 32 rows.
-// Short chunks win although each one re-blurs 2R halo rows in its prologue (tools/ubench/blur_variants.hip, 32 x 3840x2160:
-// 128-256 rows per chunk fastest at every radius, whole-height strips 2x slower): many more workgroups than resident
-// slots keeps workgroups out of phase with each other, so one's loads overlap another's arithmetic.
-static int march_chunk_rows(int /*h*/) { return 128; }
+// Rows per chunk of the marching (ring) blur: a workgroup walks its 128-column strip down one chunk in steps of 32 rows and
+// pays 2R extra horizontally blurred rows for the chunk's prologue (20 % of a 128-row chunk at R = 13).  Tall octaves take
+// 256-row chunks (tools/ubench/blur_variants.hip, 32 x 3840x2160: 2-4 % faster than 128 at every radius; whole-height strips
+// are no faster and leave a worse tail); for 1920x1080 the shorter chunks win (more workgroups than resident slots).
+static int march_chunk_rows(int h) { return h >= 1600 ? 256 : 128; }
 
 // the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 2000)
 static bool uses_march(const siftmi_ctx *c, int w, int h, int nf) {

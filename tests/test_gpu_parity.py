@@ -592,8 +592,9 @@ def _frame_slices(counts, f):
     return slice(k0, k0 + int(kc[f].sum())), slice(d0, d0 + int(dc[f].sum()))
 
 
-def test_config2_64x1080p_lockstep32_graph_replays_equal_lockstep1(sm):
-    """The bench workload itself: FrameStream over 64 x 1920x1080 frames (8 distinct), lock-step 32 (marching ring blur
+@pytest.mark.parametrize("lockstep", [32, 64])
+def test_config2_64x1080p_lockstep_graph_replays_equal_lockstep1(sm, lockstep):
+    """The bench workload itself: FrameStream over 64 x 1920x1080 frames (8 distinct), lock-step 32 / 64 (marching ring blur
     with activity flags on octaves 0 and 1, flagged-row extrema scan), direct launches on the first call, capture on the
     second, then two replays: every frame's records of every run are bit-equal to what a lock-step-1 engine (tile /
     small-launch paths, full extrema scan) returns for that frame."""
@@ -606,7 +607,7 @@ def test_config2_64x1080p_lockstep32_graph_replays_equal_lockstep1(sm):
     want = [one.detect_describe_batch(b[None]) for b in base]
     one.close()
     frames = np.stack([base[i % 8] for i in range(F)])
-    eng = sm.Engine(W, H, n_octaves=4, max_batch=32)
+    eng = sm.Engine(W, H, n_octaves=4, max_batch=lockstep)
     fs = smstream.FrameStream(eng, F, device=dev)
     d = torch.from_numpy(frames).to(dev)
     for run in range(4):
