@@ -408,246 +408,12 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Marching form of the layer blur (the shipping kernel for the Gaussian layers).  A workgroup owns a
-// 128-column strip and walks down SPC steps of S = 32 rows.  LDS holds S + 2R rows: the last 2R
-// horizontally blurred rows of the previous step are carried over (copied to the top through
-// registers), so the horizontal pass runs once per image row (the tile kernel recomputes it
-// (S+2R)/S = 1.8x at R = 13) and every input row is fetched once per strip; the next step's S input
-// rows are prefetched into registers while this step computes (loads overlap the FMA phases).
-// Same arithmetic, same tap order: bit-identical to blur2_kernel and to the oracle.
-template <int R, int S_ = 32, int NTHR_ = 256, int TW_ = 128>
-struct MarchGeom {
-    static constexpr int RP = (R + 3) & ~3;
-    static constexpr int TW = TW_, S = S_, NTHR = NTHR_, RB = S_ / (NTHR_ / (TW_ / 4));
-    static constexpr int LW = TW + 2 * RP, LH = S + 2 * R, NT = 2 * R + 1;
-    static constexpr int V = LW / 4;                                    // float4 per staged row
-    static constexpr int NPF = (S * V + NTHR - 1) / NTHR;               // prefetch float4 per lane
-    static constexpr int NCARRY = (2 * R * (TW / 4) + NTHR - 1) / NTHR; // carried float4 per lane
-    static_assert(TW == 128 || TW == 256, "strip width");
-    static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
-    static constexpr size_t lds_bytes_act = lds_bytes + (size_t)LH * 2 * sizeof(float);   // + max|Eh| per (window row, cell)
-};
-
-template <int R, int MINW = 1, int S_ = 32, bool DEC = false, bool NOBAR = false /* timing experiment only: wrong results */, int NTHR_ = 256,
-          int ABL = 0 /* timing ablation: 1 = no FMAs, 2 = no LDS reads in the two passes (wrong results) */,
-          int TW_ = 128, int VSB = 4, bool ACT = false>
-__global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
-                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
-                                                              int n_frames, int spc /* steps per chunk */, Decimate dec, Activity act) {
-    using G = MarchGeom<R, S_, NTHR_, TW_>;
-    constexpr int QW = G::TW / 4, QSH = (QW == 64 ? 6 : 5);     // float4 columns per row
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ehm = lds + G::LW * G::LH;                       // [LH][2], only with ACT (lds_bytes_act)
-    const int tid = threadIdx.x;
-    // XCD-aware 1-D order (see blur2_kernel): frame, chunk, strip with the strip index fastest
-    const int tx = (w + G::TW - 1) / G::TW;
-    const int ch_rows = spc * G::S;
-    const int nch = (h + ch_rows - 1) / ch_rows;
-    const int total = tx * nch * n_frames;
-    const int per_xcd = (total + 7) >> 3;
-    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (t >= total) return;
-    const int frame = t / (tx * nch);
-    const int rem = t - frame * (tx * nch);
-    const int chunk = rem / tx, bx = rem - chunk * tx;
-    const int x0 = bx * G::TW, ybeg = chunk * ch_rows;
-    const float *__restrict__ in = src + (size_t)frame * src_frame_stride;
-    float *__restrict__ out = dst + (size_t)frame * dst_frame_stride;
-    const bool xin = (x0 - G::RP >= 0) && (x0 + G::TW + G::RP <= w) && (w & 3) == 0;   // columns need no mirror
-
-    // general staging of window rows [r0, r1) for a step whose first output row is y0 (mirror resolved)
-    auto stage_rows = [&](int y0s, int r0, int r1) {
-        for (int idx = r0 * G::LW + tid; idx < r1 * G::LW; idx += G::NTHR) {
-            const int ly = idx / G::LW, lx = idx - ly * G::LW;
-            const int sx = symm(x0 - G::RP + lx, w), sy = symm(y0s - R + ly, h);
-            lds[idx] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : in[(size_t)sy * w + sx];
-        }
-    };
-    // rows [y, y + n) of the strip need no mirror and are 16-byte aligned -> plain float4 loads
-    auto plain = [&](int y, int n) { return xin && y >= 0 && y + n <= h; };
-
-    // prologue: stage all LH rows of the first step
-    if (plain(ybeg - R, G::LH)) {
-        const float *base = in + (size_t)(ybeg - R) * w + (x0 - G::RP);
-        for (int idx = tid; idx < G::LH * G::V; idx += G::NTHR) {
-            const int ly = idx / G::V, lv = idx - ly * G::V;
-            *reinterpret_cast<float4 *>(lds + ly * G::LW + 4 * lv) = *reinterpret_cast<const float4 *>(base + (size_t)ly * w + 4 * lv);
-        }
-    } else {
-        stage_rows(ybeg, 0, G::LH);
-    }
-    const VTaps<G::NT> tw(wt);
-
-    // Register prefetch, two steps deep: the S new input rows of step t+2 (image rows y0+2S+R ...) are
-    // requested at the start of step t and written to LDS at the end of step t+1, so every load has two
-    // steps of FMA work to land (one step was not enough: the steady-state loop ran slower than the
-    // prologue-heavy short chunks, i.e. it was waiting on memory latency).
-    auto issue_rows = [&](int ystep, f32x4 (&buf)[G::NPF]) {           // rows of the step whose first output row is ystep
-        const float *base = in + (size_t)(ystep + R) * w + (x0 - G::RP);
-#pragma unroll
-        for (int j = 0; j < G::NPF; j++) {
-            const int idx = tid + j * G::NTHR;
-            const int ly = idx / G::V, lv = idx - ly * G::V;
-            if ((j + 1) * G::NTHR <= G::S * G::V || idx < G::S * G::V)
-                buf[j] = *reinterpret_cast<const f32x4 *>(base + (size_t)ly * w + 4 * lv);
-        }
-    };
-    auto step_ok = [&](int st) { return st < spc && ybeg + st * G::S < h; };                      // step exists
-    auto step_plain = [&](int st) { return step_ok(st) && plain(ybeg + st * G::S + R, G::S); };   // ... and its new rows are plain
-    f32x4 pfA[G::NPF], pfB[G::NPF];
-    if (step_plain(1)) issue_rows(ybeg + G::S, pfB);         // consumed at the end of step 0
-
-    auto body = [&](int st, f32x4 (&pf_issue)[G::NPF], f32x4 (&pf)[G::NPF]) -> bool {
-        const int y0 = ybeg + st * G::S;                     // first output row of this step
-        const bool has_next = step_ok(st + 1);
-        const bool pf_ok = step_plain(st + 1);               // uniform; its rows were requested one step ago
-        if (!NOBAR) lds_barrier();                         // B1: window rows are in LDS
-        if (step_plain(st + 2)) issue_rows(ybeg + (st + 2) * G::S, pf_issue);
-
-        // horizontal pass, in place (first step: all LH rows; later steps: only the S new rows)
-#pragma unroll 1
-        for (int item = (st == 0 ? 0 : 2 * R * QW) + tid; item < G::LH * QW; item += G::NTHR) {
-            const int row = item >> QSH, c4 = (item & (QW - 1)) * 4;
-            float *rowp = lds + row * G::LW;
-            float v[4 + 2 * G::RP];
-            const lds_cv_f32x4 *rp4 = (const lds_cv_f32x4 *)(rowp + c4);
-#pragma unroll
-            for (int m = 0; m < (4 + 2 * G::RP) / 4; m++) {
-                f32x4 tv;
-                if (ABL >= 2) { tv.x = tv.y = tv.z = tv.w = (float)(item + m); } else tv = rp4[m];
-                v[4 * m + 0] = tv.x; v[4 * m + 1] = tv.y; v[4 * m + 2] = tv.z; v[4 * m + 3] = tv.w;
-            }
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (ABL == 1 || ABL == 3) {
-#pragma unroll
-                for (int j = 0; j < 4 + 2 * G::RP; j++) asm volatile("" ::"v"(v[j]));
-                acc[0] = v[0]; acc[1] = v[5]; acc[2] = v[9]; acc[3] = v[13];
-            } else {
-#pragma unroll
-            for (int i = 0; i < G::NT; i++) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(G::RP - R) + k + i], acc[k]);
-            }
-            }
-            *reinterpret_cast<float4 *>(rowp + G::RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            if (ACT) {                                      // max |hb - raw| over this row's 64-column cell (16 lanes x 4 columns)
-                float e = fmaxf(fmaxf(fabsf(acc[0] - v[G::RP + 0]), fabsf(acc[1] - v[G::RP + 1])),
-                                fmaxf(fabsf(acc[2] - v[G::RP + 2]), fabsf(acc[3] - v[G::RP + 3])));
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) e = fmaxf(e, __shfl_xor(e, off, 16));
-                if ((tid & 15) == 0) ehm[row * 2 + ((tid >> 4) & 1)] = e;
-            }
-        }
-        if (!NOBAR) lds_barrier();                         // B2: blurred rows complete
-
-        // vertical pass: 4 columns x RB rows per lane, taps in increasing order
-        {
-            const int cg = tid & (QW - 1), rg = tid >> QSH;
-            const float *colp = lds + (rg * G::RB) * G::LW + G::RP + cg * 4;
-            float4 cen[ACT ? G::RB : 1];                    // hb under each output (the centre tap's operand), for the activity bound
-            float4 acc[G::RB];
-#pragma unroll
-            for (int rr = 0; rr < G::RB; rr++) acc[rr] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-            for (int k = 0; k < G::RB + 2 * R; k++) {
-                if (VSB > 0 && k > 0 && (k % (VSB > 0 ? VSB : 1)) == 0) __builtin_amdgcn_sched_barrier(0);   // optional bound on the read look-ahead
-                float4 v;
-                if (ABL >= 2) v = make_float4((float)k, (float)tid, 1.0f, 2.0f); else v = *reinterpret_cast<const float4 *>(colp + k * G::LW);
-                if (ABL == 1 || ABL == 3) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); if (k < G::RB) acc[k] = v; continue; }
-#pragma unroll
-                for (int rr = 0; rr < G::RB; rr++) {
-                    const int i = k - rr;
-                    if (ACT && i == R) cen[rr] = v;
-                    if (i >= 0 && i < G::NT) {
-                        acc[rr].x = fmaf(tw.w[i], v.x, acc[rr].x);
-                        acc[rr].y = fmaf(tw.w[i], v.y, acc[rr].y);
-                        acc[rr].z = fmaf(tw.w[i], v.z, acc[rr].z);
-                        acc[rr].w = fmaf(tw.w[i], v.w, acc[rr].w);
-                    }
-                }
-            }
-            // pin the accumulators here: otherwise LLVM sinks each row's whole FMA chain into the
-            // `gy < h` store guard below, which keeps all RB+2R loaded rows live (120+ VGPRs)
-#pragma unroll
-            for (int rr = 0; rr < G::RB; rr++) asm volatile("" : "+v"(acc[rr].x), "+v"(acc[rr].y), "+v"(acc[rr].z), "+v"(acc[rr].w));
-            const int gx = x0 + cg * 4;
-#pragma unroll
-            for (int rr = 0; rr < G::RB; rr++) {
-                const int gy = y0 + rg * G::RB + rr;
-                if (gy >= h) continue;
-                float *o = out + (size_t)gy * w + gx;
-                if (gx + 3 < w && (w & 3) == 0) {
-                    *reinterpret_cast<float4 *>(o) = acc[rr];
-                } else {
-                    if (gx + 0 < w) o[0] = acc[rr].x;
-                    if (gx + 1 < w) o[1] = acc[rr].y;
-                    if (gx + 2 < w) o[2] = acc[rr].z;
-                    if (gx + 3 < w) o[3] = acc[rr].w;
-                }
-                if (DEC && (gy & 1) == 0 && (gy >> 1) < dec.h2) {
-                    float *o2 = dec.dst + (size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1);
-                    if ((gx >> 1) + 0 < dec.w2 && gx + 0 < w) o2[0] = acc[rr].x;
-                    if ((gx >> 1) + 1 < dec.w2 && gx + 2 < w) o2[1] = acc[rr].z;
-                }
-                if (ACT) {                                  // 16 lanes = 64 columns = one cell of this row
-                    static_assert(!ACT || G::TW == 128, "activity cells assume 128-column strips");
-                    const int lane = tid & 63, half = (lane >> 4) & 1;
-                    const float eh = ehm[(R + rg * G::RB + rr) * 2 + half];          // window row of this output row
-                    const float lim = act.thr * 0.9999f;
-                    const bool f = (gx + 0 < w && fabsf(acc[rr].x - cen[rr].x) + eh > lim) || (gx + 1 < w && fabsf(acc[rr].y - cen[rr].y) + eh > lim) ||
-                                   (gx + 2 < w && fabsf(acc[rr].z - cen[rr].z) + eh > lim) || (gx + 3 < w && fabsf(acc[rr].w - cen[rr].w) + eh > lim);
-                    const unsigned long long b = __ballot(f);
-                    const int cell = (x0 >> 6) + half;
-                    if ((lane & 15) == 0 && cell < act.ncell)
-                        act.dst[(size_t)frame * act.frame_stride + (size_t)gy * act.ncell + cell] = ((b >> (lane & 48)) & 0xffffull) ? 1 : 0;
-                }
-            }
-        }
-        if (!has_next) return false;                         // uniform
-
-        // carry the last 2R blurred rows (window rows S ... S+2R-1, columns RP ... RP+TW-1) to the top
-        f32x4 cr[G::NCARRY];
-#pragma unroll
-        for (int j = 0; j < G::NCARRY; j++) {
-            const int idx = tid + j * G::NTHR;
-            if (idx < 2 * R * QW) cr[j] = *reinterpret_cast<const f32x4 *>(lds + (G::S + (idx >> QSH)) * G::LW + G::RP + (idx & (QW - 1)) * 4);
-        }
-        float eh_carry = 0.0f;
-        if (ACT && tid < 4 * R) eh_carry = ehm[2 * G::S + tid];          // rows S ... S+2R-1 of max|Eh| move to the top with their rows
-        if (!NOBAR) lds_barrier();                         // B3: every read of this window is done
-        if (ACT && tid < 4 * R) ehm[tid] = eh_carry;
-#pragma unroll
-        for (int j = 0; j < G::NCARRY; j++) {
-            const int idx = tid + j * G::NTHR;
-            if (idx < 2 * R * QW) *reinterpret_cast<f32x4 *>(lds + (idx >> QSH) * G::LW + G::RP + (idx & (QW - 1)) * 4) = cr[j];
-        }
-        if (pf_ok) {
-#pragma unroll
-            for (int j = 0; j < G::NPF; j++) {
-                const int idx = tid + j * G::NTHR;
-                const int ly = idx / G::V, lv = idx - ly * G::V;
-                if ((j + 1) * G::NTHR <= G::S * G::V || idx < G::S * G::V)
-                    *reinterpret_cast<f32x4 *>(lds + (2 * R + ly) * G::LW + 4 * lv) = pf[j];
-            }
-        } else {
-            stage_rows(y0 + G::S, 2 * R, G::LH);             // border step: mirror path, straight to LDS
-        }
-        return true;
-    };
-    for (int st = 0; st < spc; st += 2) {                    // two bodies per trip: the buffers swap roles statically
-        if (!step_ok(st)) break;
-        if (!body(st, pfA, pfB)) break;
-        if (!step_ok(st + 1)) break;
-        if (!body(st + 1, pfB, pfA)) break;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ring form of the marching layer blur (round 2; replaces blur_march_kernel for the large launches).
-// Same strip walk, but the LDS window is a RING of NR = 2S rows addressed modulo NR, so nothing is carried:
-// blur_march_kernel copied the last 2R blurred rows to the top of its window through registers after every
-// step (26 rows per 16 new ones at R = 13: more LDS store traffic than the staging itself).  With the
-// LDS that frees, a step is S = 32 rows, and the vertical pass gives every wavefront ONE group of S/4 = 8
+// Marching (ring) form of the layer blur, the kernel of the large launches.  A workgroup owns a 128-column strip and walks
+// down one chunk of it in steps of S rows; the horizontal pass runs once per image row and every input row is fetched once
+// per strip (the tile kernel recomputes the horizontal pass (TH + 2R) / TH = 1.8x at R = 13).  The LDS window is a RING of
+// NR = 2S rows addressed modulo NR, so nothing is carried between steps (round 1's marching kernel copied the last 2R
+// blurred rows to the top of its window through registers after every step: 26 rows per 16 new ones at R = 13, more LDS
+// store traffic than the staging itself).  A step is S = 32 rows, and the vertical pass gives every wavefront ONE group of S/4 = 8
 // output rows with a lane owning 2 adjacent columns: the ring slot of every window row is then wave-uniform
 // (scalar address arithmetic, one v_add per read), the reads are ds_read_b64 at consecutive lanes (full LDS
 // rate at any row pitch), and a window row is read (8 + 2R)/8 times per output row instead of (2 + 2R)/2:
@@ -656,7 +422,7 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur_march_kernel(const float *__
 // Row bookkeeping: u = image row - ybeg - R.  Step st stages rows u in [st S, st S + S) into ring half
 // (st & 1); the chunk's prologue also stages u in [-2R, 0) (slots NR - 2R ... NR - 1).  Output row
 // y0 + j of step st reads u in [st S + j - 2R, st S + j].
-// Same arithmetic and tap order as blur2_kernel / blur_march_kernel: bit-identical results.
+// Same arithmetic and tap order as blur2_kernel: bit-identical results.
 template <int R, int S_ = 32>
 struct RingGeom {
     // staged halo: 8 or 16 columns per side, so that a step's S new rows are a whole number of float4 (+ one float2)

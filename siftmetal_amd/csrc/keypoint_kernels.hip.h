@@ -52,7 +52,12 @@ struct PyramidDesc {
     size_t ext_off[MAX_OCT], kp_off[MAX_OCT], desc_off[MAX_OCT];   // element offsets of the octave's segment inside a frame's segment
     size_t ext_frame, kp_frame, desc_frame;                        // elements per frame
     size_t row_off[MAX_OCT], row_frame;                            // keypoint sort: (nspo + 2) * h row buckets per octave
+    int32_t only_octave;                                           // -1: a launch covers every (frame, octave) group; o: only octave o's (grid index = frame)
 };
+
+// (frame, octave) group of a keypoint-stage workgroup: the grid index itself, or -- when a launch covers one octave only (the
+// per-octave chains of a forked single-frame graph) -- the frame index combined with that octave
+__device__ __forceinline__ int group_index(const PyramidDesc &P, int idx) { return P.only_octave < 0 ? idx : idx * P.n_octaves + P.only_octave; }
 
 struct DetectParams {              // SIFTInterpolateParameters (SIFTInterpolate.h:14-23) + literals
     float dog_threshold, edge_threshold, max_offset;
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
                                                     KeypointRec *__restrict__ kp_tmp, unsigned long long *__restrict__ kp_keys,
                                                     int32_t *__restrict__ kp_count, int32_t *__restrict__ row_count) {
     __shared__ int s_n, s_base;
-    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(cand_count[group], P.cap_ext[o]);
     const int w = P.w[o], h = P.h[o];
     const DogTex t = {layer_ptr(P, frame, o, 0), w, h, P.nspo + 2, (size_t)w * h};
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(1024) void kp_row_scan_kernel(PyramidDesc P, int32_
     // then every thread writes the starts of its run (round 1 scanned 1024 rows per trip with three barriers each: 11 trips
     // and 15 us for octave 0 of a 1080p frame, all of it latency)
     __shared__ int wsum[16];
-    const int group = blockIdx.x, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int group = group_index(P, blockIdx.x), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n_rows = (P.nspo + 2) * P.h[o];
     const size_t base = (size_t)frame * P.row_frame + P.row_off[o];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void kp_row_scatter_kernel(PyramidDesc P, cons
                                                             const int32_t *__restrict__ kp_count, const int32_t *__restrict__ row_start,
                                                             int32_t *__restrict__ row_fill, unsigned long long *__restrict__ bucket_keys,
                                                             int32_t *__restrict__ bucket_src) {
-    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
     const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o], rbase = (size_t)frame * P.row_frame + P.row_off[o];
     const unsigned int w = (unsigned int)P.w[o];
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256) void kp_row_rank_kernel(PyramidDesc P, const K
                                                          const unsigned long long *__restrict__ bucket_keys, const int32_t *__restrict__ bucket_src,
                                                          const int32_t *__restrict__ kp_count, const int32_t *__restrict__ row_start,
                                                          const int32_t *__restrict__ row_fill, KeypointRec *__restrict__ kp_sorted) {
-    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
     const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o], rbase = (size_t)frame * P.row_frame + P.row_off[o];
     const unsigned int w = (unsigned int)P.w[o];
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
     __shared__ unsigned long long hist_all[4][ORI_BINS + 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long *hist = hist_all[wv];
-    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
     const int w = P.w[o], h = P.h[o];
     const float delta = P.delta[o], lambda = prm.lambda_ori;
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P,
                                                                  int32_t *__restrict__ oriented_count) {
     __shared__ int part[1024];
     __shared__ int part2[1024];
-    const int group = blockIdx.x, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int group = group_index(P, blockIdx.x), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
     const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
     const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
     unsigned long long *patch0 = patch_all[hw_][0];
     int *col_start = col_start_all[wv];
     short *col_lo = col_lo_all[wv];
-    const int group = blockIdx.y, frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(desc_count[group], P.cap_desc[o]);
     const int w = P.w[o], h = P.h[o];
     const float delta = P.delta[o];
@@ -911,28 +916,60 @@ __global__ __launch_bounds__(256) void group_offsets_kernel(PyramidDesc P, int n
                                                            int32_t *__restrict__ out_counts /* [2][total_frames][n_oct] */,
                                                            int32_t *__restrict__ stats /* [5][total_frames][n_oct] */,
                                                            PackState *__restrict__ state, long long kp_capacity, long long desc_capacity) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // One 256-thread workgroup; the groups are scanned 256 at a time with the running totals carried in LDS.  The clamp of
+    // a group against the OUTPUT capacity depends only on the unclamped total of the groups before it (T): destination
+    // offset min(T, capacity), length clamp(capacity - T, 0, n) -- what a sequential walk with a clamped running total gives.
+    if (blockIdx.x != 0) return;
+    __shared__ long long w_k[4], w_d[4], carry_k, carry_d;
+    __shared__ int s_flags;
     const int no = P.n_octaves, ng = n_frames * no;
-    int tk = state->total_kp, td = state->total_desc, flags = state->overflow_flags;
-    for (int g = 0; g < ng; g++) {
-        const int f = g / no, o = g - f * no;
-        int nk = kp_count[g], nd = desc_count[g];
-        if (cand_count[g] > P.cap_ext[o]) flags |= 1;
-        if (nk > P.cap_kp[o]) { flags |= 2; nk = P.cap_kp[o]; }
-        if (nd > P.cap_desc[o]) { flags |= 4; nd = P.cap_desc[o]; }
-        if ((long long)tk + nk > kp_capacity) { flags |= 8; nk = (int)max(0ll, kp_capacity - tk); }
-        if ((long long)td + nd > desc_capacity) { flags |= 16; nd = (int)max(0ll, desc_capacity - td); }
-        kp_dst_off[g] = tk; desc_dst_off[g] = td;
-        const int gi = (frame_base + f) * no + o, stride = total_frames * no;
-        out_counts[gi] = nk; out_counts[stride + gi] = nd;
-        stats[0 * stride + gi] = raw_count[g];
-        stats[1 * stride + gi] = cand_count[g];
-        stats[2 * stride + gi] = kp_count[g];
-        stats[3 * stride + gi] = oriented_count[g];
-        stats[4 * stride + gi] = desc_count[g];
-        tk += nk; td += nd;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { carry_k = state->total_kp; carry_d = state->total_desc; s_flags = state->overflow_flags; }
+    __syncthreads();
+    for (int g0 = 0; g0 < ng; g0 += 256) {
+        const int g = g0 + threadIdx.x;
+        int nk = 0, nd = 0, flags = 0, o = 0, f = 0;
+        if (g < ng) {
+            f = g / no; o = g - f * no;
+            nk = kp_count[g]; nd = desc_count[g];
+            if (cand_count[g] > P.cap_ext[o]) flags |= 1;
+            if (nk > P.cap_kp[o]) { flags |= 2; nk = P.cap_kp[o]; }
+            if (nd > P.cap_desc[o]) { flags |= 4; nd = P.cap_desc[o]; }
+        }
+        long long ik = nk, id = nd;                           // inclusive wave scans
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long tk = __shfl_up(ik, d, 64), td = __shfl_up(id, d, 64);
+            if (lane >= d) { ik += tk; id += td; }
+        }
+        if (lane == 63) { w_k[wv] = ik; w_d[wv] = id; }
+        __syncthreads();
+        long long Tk = carry_k + ik - nk, Td = carry_d + id - nd;
+        for (int k = 0; k < wv; k++) { Tk += w_k[k]; Td += w_d[k]; }
+        if (g < ng) {
+            if (Tk + nk > kp_capacity) { flags |= 8; nk = (int)max(0ll, min((long long)nk, kp_capacity - Tk)); }
+            if (Td + nd > desc_capacity) { flags |= 16; nd = (int)max(0ll, min((long long)nd, desc_capacity - Td)); }
+            kp_dst_off[g] = (int)min(Tk, kp_capacity); desc_dst_off[g] = (int)min(Td, desc_capacity);
+            const int gi = (frame_base + f) * no + o, stride = total_frames * no;
+            out_counts[gi] = nk; out_counts[stride + gi] = nd;
+            stats[0 * stride + gi] = raw_count[g];
+            stats[1 * stride + gi] = cand_count[g];
+            stats[2 * stride + gi] = kp_count[g];
+            stats[3 * stride + gi] = oriented_count[g];
+            stats[4 * stride + gi] = desc_count[g];
+            if (flags) atomicOr(&s_flags, flags);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {                               // totals of this trip: all four waves
+            long long sk = 0, sd = 0;
+            for (int k = 0; k < 4; k++) { sk += w_k[k]; sd += w_d[k]; }
+            carry_k += sk; carry_d += sd;
+        }
+        __syncthreads();
     }
-    state->total_kp = tk; state->total_desc = td; state->overflow_flags = flags;
+    if (threadIdx.x == 0) {
+        state->total_kp = (int)min(carry_k, kp_capacity); state->total_desc = (int)min(carry_d, desc_capacity); state->overflow_flags = s_flags;
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(PyramidDesc P, const KeypointRec *__restrict__ kps, const DescriptorRec *__restrict__ descs,

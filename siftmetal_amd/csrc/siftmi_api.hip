@@ -341,7 +341,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
         return set_error(SIFTMI_E_BADARG, "input %dx%d too large: (nspo + 2) x octave-0 pixels must stay below 2^31", W, H);
     }
     c->frame_stride = off;
-    c->P.frame_stride = off; c->P.n_octaves = c->n_oct; c->P.nspo = nspo;
+    c->P.frame_stride = off; c->P.n_octaves = c->n_oct; c->P.nspo = nspo; c->P.only_octave = -1;
     c->P.ext_frame = ext_off; c->P.kp_frame = kp_off; c->P.desc_frame = desc_off;
     {
         size_t row_off = 0;
@@ -561,6 +561,9 @@ static int ensure_fork(siftmi_ctx *c) {
     return SIFTMI_OK;
 }
 
+static int run_refine(siftmi_ctx *c, hipStream_t st, int nf, int only_octave);
+static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave);
+
 static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
     if (c->ow[o] < 3 || c->oh[o] < 3) return SIFTMI_OK;
     // rows per workgroup, a multiple of 3 (the row loop is unrolled 3x); with activity flags one lane per window row
@@ -613,6 +616,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     // the first sub-batch of a call also clears the running totals (PackState) that sit behind the counters
     hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters,
                        5 * (size_t)c->B * c->n_oct + (first_of_call ? sizeof(PackState) / sizeof(int32_t) : 0));
+    if (fork) hipLaunchKernelGGL(zero_i32_kernel, dim3(64), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);   // for the per-octave refine launches
     t_begin(c, SIFTMI_T_SEED);
     HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed, nodec)));
     t_end(c);
@@ -645,6 +649,12 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
             }
         }
         if ((rc = launch_extrema(c, cur, nf, o))) return rc;
+        if (fork) {
+            // forked graph (a frame or two): the keypoint stages of this octave follow its extrema scan on the same chain,
+            // while the next octaves' blurs run on theirs -- octave 0's descriptors no longer wait for octave 3's pyramid
+            if ((rc = run_refine(c, cur, nf, o))) return rc;
+            if ((rc = run_describe(c, cur, nf, o))) return rc;
+        }
         if (cur != st) { HIP_TRY(hipEventRecord(c->ev_join[o], cur)); joined[o] = true; }
         cur = next;
     }
@@ -653,21 +663,24 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     return SIFTMI_OK;
 }
 
-// refine -> sort  (SIFT.swift:190-202)
-static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
-    const int groups = nf * c->n_oct;
+// refine -> sort  (SIFT.swift:190-202).  only_octave >= 0: that octave's groups only (the per-octave chains of a forked graph;
+// the row-bucket counters were cleared up front by run_dense_detect)
+static int run_refine(siftmi_ctx *c, hipStream_t st, int nf, int only_octave = -1) {
+    const int groups = only_octave < 0 ? nf * c->n_oct : nf;
+    PyramidDesc P = c->P;
+    P.only_octave = only_octave;
     StageRange rg("siftmi refine + sort (interpolateKeypoints)");
     t_begin(c, SIFTMI_T_REFINE);
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
-    hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, c->P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
+    if (only_octave < 0) hipLaunchKernelGGL(zero_i32_kernel, dim3(256), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);
+    hipLaunchKernelGGL(refine_kernel, dim3(64, groups), dim3(256), 0, st, P, c->prm, c->d_ext, cnt(c, C_CAND), c->d_kp_tmp, c->d_keys,
                        cnt(c, C_KP), c->d_row_count);
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_SORT);
-    hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, c->P, c->d_row_count, c->d_row_start);
-    hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
+    hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, P, c->d_row_count, c->d_row_start);
+    hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
                        c->d_bucket_keys, c->d_bucket_src);
-    hipLaunchKernelGGL(kp_row_rank_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp_tmp, c->d_bucket_keys, c->d_bucket_src, cnt(c, C_KP),
+    hipLaunchKernelGGL(kp_row_rank_kernel, dim3(32, groups), dim3(256), 0, st, P, c->d_kp_tmp, c->d_bucket_keys, c->d_bucket_src, cnt(c, C_KP),
                        c->d_row_start, c->d_row_count, c->d_kp);
     HIP_TRY(hipGetLastError());
     t_end(c);
@@ -675,24 +688,26 @@ static int run_refine(siftmi_ctx *c, hipStream_t st, int nf) {
 }
 
 // orientation -> expansion -> descriptors  (SIFT.swift:207-238)
-static int run_describe(siftmi_ctx *c, hipStream_t st, int nf) {
-    const int groups = nf * c->n_oct;
+static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave = -1) {
+    const int groups = only_octave < 0 ? nf * c->n_oct : nf;
+    PyramidDesc P = c->P;
+    P.only_octave = only_octave;
     StageRange rg("siftmi orientation + descriptors (getDescriptors)");
     t_begin(c, SIFTMI_T_ORIENT);
-    hipLaunchKernelGGL(orientation_kernel, dim3(256, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+    hipLaunchKernelGGL(orientation_kernel, dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                        c->d_ori_angles);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(expand_descriptors_kernel, dim3(groups), dim3(1024), 0, st, c->P, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
+    hipLaunchKernelGGL(expand_descriptors_kernel, dim3(groups), dim3(1024), 0, st, P, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
                        c->d_desc_in, cnt(c, C_DESC), cnt(c, C_ORIENTED));
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_DESCRIBE);
     // a frame or two: fewer descriptors than wavefront slots -> one workgroup per descriptor (see descriptor_kernel)
     if ((long long)nf * c->ow[0] * c->oh[0] <= 16ll * 1024 * 1024)
-        hipLaunchKernelGGL(descriptor_kernel<true>, dim3(1024, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+        hipLaunchKernelGGL(descriptor_kernel<true>, dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                            c->d_desc_f32);
     else
-        hipLaunchKernelGGL(descriptor_kernel<false>, dim3(256, groups), dim3(256), 0, st, c->P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+        hipLaunchKernelGGL(descriptor_kernel<false>, dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                            c->d_desc_f32);
     HIP_TRY(hipGetLastError());
     t_end(c);
@@ -704,7 +719,7 @@ static int run_pack(siftmi_ctx *c, hipStream_t st, int nf, int frame_base, int t
     const int groups = nf * c->n_oct;
     StageRange rg("siftmi pack results");
     t_begin(c, SIFTMI_T_PACK);
-    hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(64), 0, st, c->P, nf, frame_base, total_frames, cnt(c, C_RAW), cnt(c, C_CAND),
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(256), 0, st, c->P, nf, frame_base, total_frames, cnt(c, C_RAW), cnt(c, C_CAND),
                        cnt(c, C_KP), cnt(c, C_ORIENTED), cnt(c, C_DESC), c->d_dst_off, c->d_dst_off + (size_t)c->B * c->n_oct, d_counts,
                        d_stats, c->d_state, kp_cap, desc_cap);
     HIP_TRY(hipGetLastError());
@@ -761,8 +776,10 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
         const int nf = std::min(c->B, n_frames - f0);
         const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
         if ((rc = run_dense_detect(c, st, nf, px, format, row_stride, frame_stride, fork, f0 == 0))) return rc;
-        if ((rc = run_refine(c, st, nf))) return rc;
-        if ((rc = run_describe(c, st, nf))) return rc;
+        if (!fork) {                                       // forked: the per-octave chains ran them (run_dense_detect)
+            if ((rc = run_refine(c, st, nf, -1))) return rc;
+            if ((rc = run_describe(c, st, nf, -1))) return rc;
+        }
         if ((rc = run_pack(c, st, nf, f0, n_frames, d_kp, kp_cap, d_desc, desc_cap, d_counts, c->d_stats))) return rc;
         c->last_sub_frames = nf;
     }

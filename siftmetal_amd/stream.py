@@ -2,28 +2,60 @@
 all-gather of the packed results.  The HIP path runs on a launch stream owned by the FrameStream, ordered after torch's
 current stream on entry and before it on exit, so torch work issued before run() (the frame upload) and after it
 (`.cpu()`, collectives) is ordered with the kernels whatever torch's current stream is -- including the default stream,
-whose handle is NULL and would otherwise select the context's own, unordered stream."""
+whose handle is NULL and would otherwise select the context's own, unordered stream.
+
+With `overlap_gather` (the multi-GPU driver) the packed results alternate between TWO buffer sets and the all-gather of
+step k runs on a side stream: the kernels of step k+1 write the other set while RCCL reads this one over xGMI, so the
+exchange (7 peers x ~30 MB per rank and step on the fully connected mesh: a few ms, per-link bound) hides under compute
+instead of adding to every step.  A set is reused two steps later, after its gather has finished (event)."""
 import numpy as np
 import torch
 
 from . import _capi, dist as smdist
 
 
+class _ResultSet:
+    def __init__(self, kp_cap, desc_cap, frames, n_octaves, device):
+        self.kp = torch.empty(kp_cap * smdist.KP_BYTES, dtype=torch.uint8, device=device)
+        self.desc = torch.empty(desc_cap * smdist.DESC_BYTES, dtype=torch.uint8, device=device)
+        self.counts = torch.zeros((2, frames, n_octaves), dtype=torch.int32, device=device)
+        self.totals = torch.zeros(4, dtype=torch.int32, device=device)      # {n_kp, n_desc, overflow flags, 0}
+        self.gather_done = None                                             # event: the side-stream gather that read this set
+
+
 class FrameStream:
-    def __init__(self, engine, frames_per_step, device, world_size=1, kp_per_frame=32768, desc_per_frame=49152):
+    def __init__(self, engine, frames_per_step, device, world_size=1, kp_per_frame=32768, desc_per_frame=49152, overlap_gather=False):
         self.eng = engine
         self.F = frames_per_step
         self.device = device
         self.world = world_size
         self.kp_cap = kp_per_frame * frames_per_step
         self.desc_cap = desc_per_frame * frames_per_step
-        self.kp = torch.empty(self.kp_cap * smdist.KP_BYTES, dtype=torch.uint8, device=device)
-        self.desc = torch.empty(self.desc_cap * smdist.DESC_BYTES, dtype=torch.uint8, device=device)
-        self.counts = torch.zeros((2, frames_per_step, engine.n_octaves), dtype=torch.int32, device=device)
-        self.totals = torch.zeros(4, dtype=torch.int32, device=device)      # {n_kp, n_desc, overflow flags, 0}
+        self.overlap = bool(overlap_gather)
+        self.sets = [_ResultSet(self.kp_cap, self.desc_cap, frames_per_step, engine.n_octaves, device) for _ in range(2 if self.overlap else 1)]
+        self.cur = 0                                         # the set the last run() wrote
         self.gathered = None
         self.exchange = smdist.ResultExchange(self.kp_cap, self.desc_cap)
         self.launch_stream = torch.cuda.Stream(device=device)
+        self.gather_stream = torch.cuda.Stream(device=device) if self.overlap else None
+        self.gather_events = []                              # (start, end) timing events of every all_gather() call
+
+    # the buffers of the last step (what results_host / all_gather read)
+    @property
+    def kp(self):
+        return self.sets[self.cur].kp
+
+    @property
+    def desc(self):
+        return self.sets[self.cur].desc
+
+    @property
+    def counts(self):
+        return self.sets[self.cur].counts
+
+    @property
+    def totals(self):
+        return self.sets[self.cur].totals
 
     def run(self, d_frames):
         """d_frames: uint8 [F, H, W, 4] (BGRA) / [F, H, W] (gray) or float32 [F, H, W] device tensor."""
@@ -35,29 +67,57 @@ class FrameStream:
         else:
             fmt = _capi.FMT_GRAYF32
         es = d_frames.element_size()
+        if self.overlap:
+            self.cur ^= 1
+        rs = self.sets[self.cur]
         cur = torch.cuda.current_stream(self.device)
         self.launch_stream.wait_stream(cur)
+        if rs.gather_done is not None:                       # the gather that read this set two steps ago
+            self.launch_stream.wait_event(rs.gather_done)
         d_frames.record_stream(self.launch_stream)
         self.eng.detect_describe_batch_device(self.F, d_frames.data_ptr(), fmt, d_frames.stride(1) * es, d_frames.stride(0) * es,
-                                              self.kp.data_ptr(), self.kp_cap, self.desc.data_ptr(), self.desc_cap,
-                                              self.counts.data_ptr(), self.totals.data_ptr(), self.launch_stream.cuda_stream)
+                                              rs.kp.data_ptr(), self.kp_cap, rs.desc.data_ptr(), self.desc_cap,
+                                              rs.counts.data_ptr(), rs.totals.data_ptr(), self.launch_stream.cuda_stream)
         cur.wait_stream(self.launch_stream)
 
     def all_gather(self, synchronous=False):
-        """RCCL all-gather of this step's packed results.  Default: payload sizes come from the previous step's counts, so
-        nothing synchronises the host inside the step (ResultExchange); synchronous=True sizes them from this step's."""
-        if synchronous:
-            self.gathered = smdist.gather_results(self.kp, self.desc, self.counts, self.totals)
+        """RCCL all-gather of the last step's packed results.  Default: payload sizes come from the previous step's counts, so
+        nothing synchronises the host inside the step (ResultExchange); synchronous=True sizes them from this step's.
+        With overlap_gather the collectives run on the side stream: call wait_gather() (or synchronise the device) before
+        reading the returned tensors."""
+        rs = self.sets[self.cur]
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if self.overlap and not synchronous:
+            self.gather_stream.wait_stream(self.launch_stream)
+            with torch.cuda.stream(self.gather_stream):
+                t0.record()
+                self.gathered = self.exchange.gather(rs.kp, rs.desc, rs.counts, rs.totals)
+                t1.record()
+                rs.gather_done = torch.cuda.Event()
+                rs.gather_done.record(self.gather_stream)
         else:
-            self.gathered = self.exchange.gather(self.kp, self.desc, self.counts, self.totals)
+            t0.record()
+            if synchronous:
+                self.gathered = smdist.gather_results(rs.kp, rs.desc, rs.counts, rs.totals)
+            else:
+                self.gathered = self.exchange.gather(rs.kp, rs.desc, rs.counts, rs.totals)
+            t1.record()
+        self.gather_events.append((t0, t1))
+        del self.gather_events[:-64]
         return self.gathered
 
+    def wait_gather(self):
+        """Order torch's current stream after the side-stream gather (no host synchronisation)."""
+        if self.overlap:
+            torch.cuda.current_stream(self.device).wait_stream(self.gather_stream)
+
     def results_host(self, allow_capacity=False):
-        tot = self.totals.cpu().numpy()
+        rs = self.sets[self.cur]
+        tot = rs.totals.cpu().numpy()
         nk, nd = int(tot[0]), int(tot[1])
         if tot[2] and not allow_capacity:       # the condition the host-facing API reports as SIFTMI_E_CAPACITY
             raise _capi.SiftmiError(_capi.E_CAPACITY, "list capacity exceeded on the device path (overflow flags 0x%x): results truncated" % int(tot[2]))
-        kp = self.kp[:nk * smdist.KP_BYTES].cpu().numpy().view(_capi.keypoint_dtype)
-        ds = self.desc[:nd * smdist.DESC_BYTES].cpu().numpy().view(_capi.descriptor_dtype)
-        return {"n_keypoints": nk, "n_descriptors": nd, "keypoints": kp, "descriptors": ds, "counts": self.counts.cpu().numpy(),
+        kp = rs.kp[:nk * smdist.KP_BYTES].cpu().numpy().view(_capi.keypoint_dtype)
+        ds = rs.desc[:nd * smdist.DESC_BYTES].cpu().numpy().view(_capi.descriptor_dtype)
+        return {"n_keypoints": nk, "n_descriptors": nd, "keypoints": kp, "descriptors": ds, "counts": rs.counts.cpu().numpy(),
                 "overflow_flags": int(tot[2])}

@@ -681,3 +681,40 @@ def test_device_path_reports_overflow_and_orders_following_calls(sm):
         r = fs.results_host()
         assert r["keypoints"].tobytes() == want[0].tobytes() and r["descriptors"].tobytes() == want[2].tobytes()
     eng.close()
+
+
+def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm):
+    """The multi-GPU driver's exchange path on one rank through RCCL: double-buffered result sets, the all-gather of step k on
+    a side stream under the kernels of step k+1, payload sizes taken from the previous step.  Every step's gathered row must
+    be exactly that step's own packed results (alternating frame sets make consecutive steps differ)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from siftmetal_amd import dist as smdist, stream as smstream
+    dev = torch.device("cuda", 0)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        fa = np.stack([blob_frame(640, 480, i) for i in range(4)])
+        fb = np.stack([blob_frame(640, 480, 10 + i, n_blobs=300) for i in range(4)])
+        eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
+        want = [eng.detect_describe_batch(f) for f in (fa, fb)]
+        fs = smstream.FrameStream(eng, 4, device=dev, overlap_gather=True)
+        da, db = torch.from_numpy(fa).to(dev), torch.from_numpy(fb).to(dev)
+        gathered = []
+        for step in range(8):
+            fs.run(da if step % 2 == 0 else db)
+            gathered.append(fs.all_gather())
+        torch.cuda.synchronize()
+        incomplete, overflow = fs.exchange.finish()
+        assert incomplete == [] and overflow == []
+        for step, g in enumerate(gathered):
+            k, kc, d, dc = want[step % 2]
+            tot = g["totals_device"].cpu().numpy()
+            assert tot[0, 0] == len(k) and tot[0, 1] == len(d) and tot[0, 2] == 0
+            assert g["keypoints"][0, :len(k) * smdist.KP_BYTES].cpu().numpy().tobytes() == k.tobytes(), step
+            assert g["descriptors"][0, :len(d) * smdist.DESC_BYTES].cpu().numpy().tobytes() == d.tobytes(), step
+            assert np.array_equal(g["counts"][0, 0].cpu().numpy(), kc) and np.array_equal(g["counts"][0, 1].cpu().numpy(), dc)
+        eng.close()
+    finally:
+        dist.destroy_process_group()

@@ -72,17 +72,12 @@ static void bench_R(Ctx &c, float rho) {
     CHECK(hipDeviceSynchronize());
     SeedSource none; memset(&none, 0, sizeof(none)); Decimate nodec; memset(&nodec, 0, sizeof(nodec));
     Activity noact{nullptr, 0, 0, 0.0f};
-    // round-1 shipping kernels for reference: tile form and marching form (S = 16, carry copy)
+    // tile form (small octaves, single frames)
 #define V2X(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
         const int total = ((c.w + G::TW - 1) / G::TW) * ((c.h + G::TH - 1) / G::TH) * c.nf; \
         dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("tile TH=" #TH_ " RB=" #RB_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec); }); }
     V2X(32, 256, 4, 1, 0)
-#define VM(SPC_, MINW_, S_) { using G = MarchGeom<R, S_>; \
-        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + SPC_ * G::S - 1) / (SPC_ * G::S); \
-        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("march S=" #S_ " spc=" #SPC_ " minw=" #MINW_, c, R, [&] { hipLaunchKernelGGL((blur_march_kernel<R, MINW_, S_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, SPC_, nodec, noact); }); }
-    VM(8, 4, 16)
     // round 2: ring form
 #define VR(S_, CHR_, MINW_, DBG_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
