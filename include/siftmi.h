@@ -257,8 +257,9 @@ int siftmi_reset_timings(siftmi_ctx *ctx);
 int siftmi_get_timings(siftmi_ctx *ctx, double *ms /*[SIFTMI_T_COUNT]*/, int64_t *launches /*[SIFTMI_T_COUNT]*/);
 /* algorithmic bytes one blur launch of `octave` moves for ONE frame: 8 B per octave pixel */
 int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *ctx, int octave);
-/* runs the Gaussian-layer blur kernel alone (layer 1..nspo+2 of `octave`, all max_batch frames)
-   `iters` times on the resident pyramid and returns the mean kernel time in ms (hipEvents) */
+/* runs the Gaussian-layer blur launch of the pipeline alone (layer 1..nspo+2 of `octave`, all max_batch frames, with the
+   decimated / activity-flag outputs the pipeline gives that layer) `iters` times on the resident pyramid and returns the
+   mean kernel time in ms (hipEvents) */
 int siftmi_time_blur(siftmi_ctx *ctx, int octave, int layer, int iters, double *ms_per_launch);
 int siftmi_synchronize(siftmi_ctx *ctx);
 

@@ -457,7 +457,9 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 // with the max over lanes i-15 ... i; lanes without a source keep their own value).  Pure VALU: __shfl_xor goes through
 // the LDS crossbar (ds_swizzle / ds_bpermute) and this runs once per horizontal-pass item.
 __device__ __forceinline__ float row16_max_to_lane15(float e) {
-#define SIFTMI_DPP_MAX(ctrl) e = fmaxf(e, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, e), ctrl, 0xf, 0xf, false)))
+    // bound_ctrl with old = 0: lanes without a source read 0, the identity of max over non-negative values, which lets the
+    // compiler fold the move into v_max_f32_dpp (one instruction per step instead of two)
+#define SIFTMI_DPP_MAX(ctrl) e = fmaxf(e, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), ctrl, 0xf, 0xf, true)))
     SIFTMI_DPP_MAX(0x111); SIFTMI_DPP_MAX(0x112); SIFTMI_DPP_MAX(0x114); SIFTMI_DPP_MAX(0x118);
 #undef SIFTMI_DPP_MAX
     return e;
@@ -681,8 +683,8 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             *reinterpret_cast<float4 *>(rowp + RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             if (ACT) {                                      // max |hb - raw| over this row's 64-column cell (16 lanes x 4 columns)
                 constexpr int C = RP - 4 * M0;
-                const float e = row16_max_to_lane15(fmaxf(fmaxf(fabsf(acc[0] - v[C + 0]), fabsf(acc[1] - v[C + 1])),
-                                                          fmaxf(fabsf(acc[2] - v[C + 2]), fabsf(acc[3] - v[C + 3]))));
+                const float e = row16_max_to_lane15(fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(acc[0] - v[C + 0]), fabsf(acc[1] - v[C + 1])), fabsf(acc[2] - v[C + 2])),
+                                                          fabsf(acc[3] - v[C + 3])));
                 if ((tid & 15) == 15) ehm(slot, (tid >> 4) & 1) = e;
             }
         }
@@ -716,6 +718,11 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
 #pragma unroll
             for (int rr = 0; rr < RB; rr++) asm volatile("" : "+v"(acc[rr].x), "+v"(acc[rr].y));
             unsigned act_mask = 0;                          // wave-uniform: bit rr / RB + rr = cell 0 / 1 of output row rr is active
+            float eh_row[ACT ? RB : 1];                     // max|Eh| of this lane's cell under each output row: all RB LDS reads in one batch
+            if (ACT) {
+#pragma unroll
+                for (int rr = 0; rr < RB; rr++) eh_row[rr] = ehm((st * S + wv * RB + rr - R + NR) & (NR - 1), lane >> 5);
+            }
             stamp(3);
             const int gx = x0 + 2 * lane;
 #pragma unroll
@@ -734,9 +741,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                         dec.dst[(size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1)] = acc[rr].x;
                 }
                 if (ACT) {                                  // 32 lanes = 64 columns = one cell of this row
-                    const int half = lane >> 5;
-                    const int slot_c = (st * S + wv * RB + rr - R + NR) & (NR - 1);           // ring row under this output row
-                    const float eh = ehm(slot_c, half);
+                    const float eh = eh_row[rr];            // ring row (st S + wv RB + rr - R) under this output row
                     const float lim = act.thr * 0.9999f;
                     const bool f = ((FULL || gx + 0 < w) && fabsf(acc[rr].x - cen[rr].x) + eh > lim) ||
                                    ((FULL || gx + 1 < w) && fabsf(acc[rr].y - cen[rr].y) + eh > lim);
@@ -777,8 +782,12 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
     const bool strip_full = colfast && x0 + G::TW <= w && (!DEC || ((ybeg & 1) == 0 && (S & 1) == 0));
     for (int st = 0; st < nst; st++) {
         const int y0 = ybeg + st * S;
+#ifdef SIFTMI_RING_NO_MODE1                                  // tools/ubench experiment only
+        const bool pre = false;
+#else
         const bool pre = colfast && st + 1 < nst;
-        const bool full = pre && strip_full && y0 + S <= h && (!DEC || ((y0 + S - 1) >> 1) < dec.h2);
+#endif
+        const bool full = colfast && st + 1 < nst && strip_full && y0 + S <= h && (!DEC || ((y0 + S - 1) >> 1) < dec.h2);
         if (full) body(std::integral_constant<int, 2>{}, st);
         else if (pre) body(std::integral_constant<int, 1>{}, st);
         else body(std::integral_constant<int, 0>{}, st);

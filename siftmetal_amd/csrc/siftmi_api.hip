@@ -1449,9 +1449,18 @@ extern "C" int siftmi_time_blur(siftmi_ctx *c, int o, int layer, int iters, doub
     }
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, c->stream));
+    // the launch exactly as the pipeline issues it (run_dense_detect): the layer that feeds the next octave also writes its
+    // decimated copy, layers 2 ... nspo+1 of a marching-blur octave also write the extrema activity flags
+    Decimate dec = nodec;
+    if (layer == c->nspo && o + 1 < c->n_oct) {
+        dec.dst = gauss_ptr(c, o + 1, 0); dec.frame_stride = c->frame_stride; dec.w2 = c->ow[o + 1]; dec.h2 = c->oh[o + 1];
+    }
+    Activity act{nullptr, 0, 0, 0.0f};
+    if (!c->cfg.count_raw_extrema && c->ow[o] >= 3 && c->oh[o] >= 3 && uses_march(c, c->ow[o], c->oh[o], c->B) && layer >= 2 && layer <= c->nspo + 1)
+        act = Activity{c->d_act + c->act_off[o] + (size_t)(layer - 2) * c->oh[o] * c->act_ncell[o], c->act_frame, c->act_ncell[o], c->prm.dog_threshold * 0.8f};
     for (int i = 0; i < iters; i++)
         HIP_TRY((launch_blur<false>(c, c->stream, (c->taps[layer - 1] - 1) / 2, gauss_ptr(c, o, layer - 1), gauss_ptr(c, o, layer), c->ow[o],
-                                    c->oh[o], c->B, c->layer_w[layer - 1], none, nodec)));
+                                    c->oh[o], c->B, c->layer_w[layer - 1], none, dec, act)));
     HIP_TRY(hipEventRecord(b, c->stream));
     HIP_TRY(hipEventSynchronize(b));
     float ms = 0.0f;
