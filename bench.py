@@ -353,6 +353,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()                                      # rank 0's extra measurements are done: all ranks leave together
         dist.destroy_process_group()
 
 

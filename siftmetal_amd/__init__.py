@@ -174,7 +174,9 @@ class Engine:
 
     # ---- SIFT.getKeypoints / getDescriptors at array level ----
     def detect(self, img, allow_capacity=False):
-        img = np.ascontiguousarray(img)
+        # rows may be strided (a view into a wider buffer: the C ABI takes a row stride); pixels of a row must be contiguous
+        if not (img.strides[-1] == img.itemsize and (img.ndim == 2 or img.strides[1] == img.shape[2] * img.itemsize) and img.strides[0] > 0):
+            img = np.ascontiguousarray(img)
         assert img.shape[0] == self.height and img.shape[1] == self.width, "image size != configured inputSize"
         out = C.c_void_p()
         counts = np.zeros(self.n_octaves, np.int32)

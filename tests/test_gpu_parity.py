@@ -149,10 +149,13 @@ def test_batch_equals_single_and_is_deterministic(sm):
     assert kpos == len(a[0]) and dpos == len(a[2]) and dpos > 100
 
 
-def test_formats_agree(sm):
+@pytest.mark.parametrize("mode", ["default", "march_skip"])
+def test_formats_agree(sm, mode):
+    """GRAY8, GRAYF32 and BGRA8 inputs of the same picture, through the tile seed kernel (default) and through the marching
+    seed kernel's three format instantiations (march_skip); also strided rows (a sub-rectangle view of a wider buffer)."""
     g = blob_frame(200, 160, 4, gray=True)
     bgra = np.ascontiguousarray(np.repeat(g[..., None], 4, 2))
-    eng = sm.Engine(200, 160, n_octaves=3)
+    eng = sm.Engine(200, 160, n_octaves=3, **MODES[mode])
     r8 = eng.detect_describe_batch(g[None])
     G8 = eng.gaussian(0, 3)
     rf = eng.detect_describe_batch((g.astype(np.float32) / np.float32(255))[None])
@@ -162,6 +165,19 @@ def test_formats_agree(sm):
     rb = eng.detect_describe_batch(bgra[None])
     assert np.abs(eng.gaussian(0, 3) - G8).max() < 3e-7          # luma weights sum to 1 within f32 rounding
     assert abs(len(rb[0]) - len(r8[0])) <= 2
+    # the oracle on each format: Gaussian stack bit-identical
+    for img in (g, (g.astype(np.float32) / np.float32(255)), bgra):
+        eng.detect_describe_batch(img[None])
+        orc = _oracle(200, 160, 3)
+        orc.build_pyramid(img)
+        for o in range(3):
+            assert np.array_equal(eng.gaussian(o, 0), orc.gaussian(o, 0)) and np.array_equal(eng.gaussian(o, 5), orc.gaussian(o, 5)), (str(img.dtype), img.shape, o)
+    # strided input rows through siftmi_detect (row_stride > width * bytes per pixel)
+    wide = np.zeros((160, 260, 4), np.uint8)
+    wide[:, 30:230] = bgra
+    k1, c1 = eng.detect(wide[:, 30:230])
+    k2, c2 = eng.detect(bgra)
+    assert np.array_equal(c1, c2) and k1.tobytes() == k2.tobytes()
 
 
 def test_errors_and_capacity(sm):
