@@ -261,6 +261,19 @@ def main():
         achieved = total_bytes / (blur_ms * 1e-3) / 1e9 if blur_ms > 0 else 0.0
         stage_ms = {k: round(v[0] / args.steps, 4) for k, v in tm.items()}
         log("stage ms/step:", stage_ms)
+        # the same time split by launch shape = (octave, layer): one kernel instantiation and grid each, comparable row by
+        # row with profiles/rocprof_kernel_shapes_rNN.csv (the kernel trace of this command, tools/profile_round.sh)
+        shapes = {}
+        for o in range(N_OCT):
+            for layer in range(1, NSPO + 3):
+                ms, n, marching = eng.blur_layer_timings(o, layer)
+                if n:
+                    radius = len(eng.weights(layer)) // 2
+                    nbytes = eng.blur_algorithmic_bytes(o) * eng.max_batch
+                    shapes["o%d_l%d" % (o, layer)] = {"kernel": ("blur_ring_kernel<%d, ...>" if marching else "blur2_kernel<%d, ...>") % radius,
+                                                     "decimating": layer == NSPO and o + 1 < N_OCT, "activity_flags": bool(marching and 2 <= layer <= NSPO + 1),
+                                                     "launches": n, "avg_launch_us": round(ms / n * 1e3, 2),
+                                                     "GBps": round(nbytes / (ms / n * 1e-3) / 1e9, 1)}
         per_layer = {}
         for layer in range(1, NSPO + 3):
             ms = eng.time_blur(0, layer, 10)
@@ -285,7 +298,7 @@ def main():
                            "traffic_source": traffic_src, "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBS, 4),
                            "launches": blur_n, "avg_launch_ms": round(blur_ms / max(blur_n, 1), 5),
                            "algorithmic_bytes_per_launch_avg": int(total_bytes / max(blur_n, 1)),
-                           "octave0_GBps_by_layer": per_layer, "stage_ms_per_step": stage_ms,
+                           "octave0_GBps_by_layer": per_layer, "by_launch_shape": shapes, "stage_ms_per_step": stage_ms,
                            "measured_in": "second identical pass of K steps, hipEvents around every launch on the launch stream"}
     if rank == 0 and not args.no_extras:
         # BASELINE configs[1]: ONE 1920x1080 frame per call (lock-step batch 1, hipGraph replay), frame in HBM

@@ -255,6 +255,10 @@ enum { SIFTMI_T_SEED = 0, SIFTMI_T_BLUR = 1, SIFTMI_T_DOWNSAMPLE = 2 /* always 0
 int siftmi_enable_timings(siftmi_ctx *ctx, int enable);
 int siftmi_reset_timings(siftmi_ctx *ctx);
 int siftmi_get_timings(siftmi_ctx *ctx, double *ms /*[SIFTMI_T_COUNT]*/, int64_t *launches /*[SIFTMI_T_COUNT]*/);
+/* the SIFTMI_T_BLUR time split by (octave, layer 1..nspo+2): accumulated ms and launch count of that layer's blur launches
+   since the last reset -- one kernel instantiation and grid size each, so that a rocprofv3 kernel trace of the same command
+   can be compared launch shape by launch shape; *marching = 1 if those launches use blur_ring_kernel, 0 for blur2_kernel */
+int siftmi_get_blur_layer_timings(siftmi_ctx *ctx, int octave, int layer, double *ms, int64_t *launches, int32_t *marching);
 /* algorithmic bytes one blur launch of `octave` moves for ONE frame: 8 B per octave pixel */
 int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *ctx, int octave);
 /* runs the Gaussian-layer blur launch of the pipeline alone (layer 1..nspo+2 of `octave`, all max_batch frames, with the

@@ -313,6 +313,12 @@ class Engine:
         _capi.check(self.L.siftmi_get_timings(self.h, ms.ctypes.data, n.ctypes.data))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_capi.T_NAMES)}
 
+    def blur_layer_timings(self, o, layer):
+        """(accumulated ms, launches, uses the marching kernel) of the blur launches of (octave, layer) since reset_timings."""
+        ms, n, m = C.c_double(), C.c_int64(), C.c_int32()
+        _capi.check(self.L.siftmi_get_blur_layer_timings(self.h, o, layer, C.byref(ms), C.byref(n), C.byref(m)))
+        return ms.value, n.value, bool(m.value)
+
     def blur_algorithmic_bytes(self, o):
         return int(self.L.siftmi_blur_algorithmic_bytes(self.h, o))
 

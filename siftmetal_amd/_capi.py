@@ -18,7 +18,7 @@ EXPORTS = [
     "siftmi_descriptor_to_reference", "siftmi_host_alloc", "siftmi_host_free", "siftmi_match_descriptors", "siftmi_approximate_match", "siftmi_match_geometry", "siftmi_descriptor_index", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
     "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_dog", "siftmi_copy_extrema", "siftmi_copy_orientations",
     "siftmi_copy_descriptor_floats", "siftmi_enable_timings", "siftmi_reset_timings", "siftmi_get_timings",
-    "siftmi_blur_algorithmic_bytes", "siftmi_time_blur", "siftmi_synchronize",
+    "siftmi_blur_algorithmic_bytes", "siftmi_get_blur_layer_timings", "siftmi_time_blur", "siftmi_synchronize",
 ]
 
 
@@ -102,6 +102,7 @@ def load():
     L.siftmi_enable_timings.argtypes = [vp, C.c_int]
     L.siftmi_reset_timings.argtypes = [vp]
     L.siftmi_get_timings.argtypes = [vp, vp, vp]
+    L.siftmi_get_blur_layer_timings.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32p]
     L.siftmi_blur_algorithmic_bytes.argtypes = [vp, C.c_int]
     L.siftmi_blur_algorithmic_bytes.restype = C.c_int64
     L.siftmi_time_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]

@@ -76,7 +76,7 @@ struct StageRange {                            // host-side range around the lau
     ~StageRange() { if (on) roctx().pop(); }
 };
 
-struct EventPair { hipEvent_t a, b; int stage; };
+struct EventPair { hipEvent_t a, b; int stage; int sub; };     // sub: octave * 8 + layer for the layer blurs, else -1
 
 struct siftmi_ctx {
     siftmi_config cfg;
@@ -181,6 +181,8 @@ struct siftmi_ctx {
     std::vector<EventPair> pending, pool;
     double t_ms[SIFTMI_T_COUNT];
     int64_t t_launches[SIFTMI_T_COUNT];
+    double t_blur_ms[MAX_OCT][8];             // the SIFTMI_T_BLUR time split by (octave, layer): one kernel name and grid each
+    int64_t t_blur_launches[MAX_OCT][8];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -287,6 +289,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     c->n_oct = cfg->n_octaves; c->nspo = cfg->nspo; c->B = cfg->max_batch;
     c->march_min_blocks = cfg->blur_march_min_blocks > 0 ? cfg->blur_march_min_blocks : 2000;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_launches, 0, sizeof(c->t_launches));
+    memset(c->t_blur_ms, 0, sizeof(c->t_blur_ms)); memset(c->t_blur_launches, 0, sizeof(c->t_blur_launches));
     const int W = cfg->width, H = cfg->height, nspo = cfg->nspo, NG = nspo + 3;
 
     // --- schedule: DifferenceOfGaussians.swift:235-238, 255-262, 315-328, Octave.init :91-102
@@ -426,12 +429,13 @@ static int order_sync(siftmi_ctx *c) {
 
 // ------------------------------------------------------------------------------------------------
 // timing helpers
-static void t_begin(siftmi_ctx *c, int stage) {
+static void t_begin(siftmi_ctx *c, int stage, int sub = -1) {
     if (!c->timing) return;
     EventPair ep;
     if (!c->pool.empty()) { ep = c->pool.back(); c->pool.pop_back(); }
     else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
     ep.stage = stage;
+    ep.sub = sub;
     (void)hipEventRecord(ep.a, c->tstream ? c->tstream : c->stream);
     c->pending.push_back(ep);
 }
@@ -445,6 +449,7 @@ static void t_collect(siftmi_ctx *c) {
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             c->t_ms[ep.stage] += ms;
             c->t_launches[ep.stage] += 1;
+            if (ep.stage == SIFTMI_T_BLUR && ep.sub >= 0) { c->t_blur_ms[ep.sub >> 3][ep.sub & 7] += ms; c->t_blur_launches[ep.sub >> 3][ep.sub & 7] += 1; }
         }
         c->pool.push_back(ep);
     }
@@ -638,7 +643,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
             if (c->act_valid[o] && s >= 2 && s <= c->nspo + 1)
                 act = Activity{c->d_act + c->act_off[o] + (size_t)(s - 2) * c->oh[o] * c->act_ncell[o], c->act_frame, c->act_ncell[o],
                                c->prm.dog_threshold * 0.8f};
-            t_begin(c, SIFTMI_T_BLUR);
+            t_begin(c, SIFTMI_T_BLUR, o * 8 + s);
             HIP_TRY((launch_blur<false>(c, cur, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
                                         nf, c->layer_w[s - 1], none, dec, act)));
             t_end(c);
@@ -1423,6 +1428,7 @@ extern "C" int siftmi_reset_timings(siftmi_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     t_collect(c);
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_launches, 0, sizeof(c->t_launches));
+    memset(c->t_blur_ms, 0, sizeof(c->t_blur_ms)); memset(c->t_blur_launches, 0, sizeof(c->t_blur_launches));
     return SIFTMI_OK;
 }
 extern "C" int siftmi_get_timings(siftmi_ctx *c, double *ms, int64_t *launches) {
@@ -1430,6 +1436,15 @@ extern "C" int siftmi_get_timings(siftmi_ctx *c, double *ms, int64_t *launches) 
     HIP_TRY(hipSetDevice(c->device));
     t_collect(c);
     for (int i = 0; i < SIFTMI_T_COUNT; i++) { if (ms) ms[i] = c->t_ms[i]; if (launches) launches[i] = c->t_launches[i]; }
+    return SIFTMI_OK;
+}
+extern "C" int siftmi_get_blur_layer_timings(siftmi_ctx *c, int o, int layer, double *ms, int64_t *launches, int32_t *marching) {
+    if (!c || o < 0 || o >= c->n_oct || layer < 1 || layer > c->nspo + 2) return set_error(SIFTMI_E_BADARG, "bad octave/layer");
+    HIP_TRY(hipSetDevice(c->device));
+    t_collect(c);
+    if (ms) *ms = c->t_blur_ms[o][layer];
+    if (launches) *launches = c->t_blur_launches[o][layer];
+    if (marching) *marching = uses_march(c, c->ow[o], c->oh[o], std::min(c->B, std::max(c->last_frames, 1))) ? 1 : 0;
     return SIFTMI_OK;
 }
 extern "C" int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *c, int o) {

@@ -24,6 +24,19 @@ rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(out + "/rocprof_kernel_stats_%s.csv" % tag, "w") as f:
     if rows:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+# per launch shape (kernel name x grid): the kernel-trace rows of the same run grouped like bench.py's roofline.by_launch_shape
+trace = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)
+if trace:
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace[0])):
+        n = r["Kernel_Name"]
+        short = (n[:n.index("(")] if "(" in n else n).replace("void siftmi::", "").replace("siftmi::", "")
+        d[(short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(out + "/rocprof_kernel_shapes_%s.csv" % tag, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "workgroups_x", "grid_y", "grid_z", "calls", "avg_us", "min_us", "max_us", "total_ms"])
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k[0], k[1], k[2], k[3], len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2), round(sum(v) / 1e6, 3)])
 for r in rows[:16]:
     print("%-74s calls %6s total_ns %12s avg_ns %10s pct %s" % (r.get("Name", "")[:74], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 
