@@ -465,6 +465,13 @@ __device__ __forceinline__ float row16_max_to_lane15(float e) {
     return e;
 }
 
+__device__ __forceinline__ float row8_max_to_lane7(float e) {      // the same over groups of 8 lanes: valid in lanes 7 and 15 of a DPP row
+#define SIFTMI_DPP_MAX(ctrl) e = fmaxf(e, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), ctrl, 0xf, 0xf, true)))
+    SIFTMI_DPP_MAX(0x111); SIFTMI_DPP_MAX(0x112); SIFTMI_DPP_MAX(0x114);
+#undef SIFTMI_DPP_MAX
+    return e;
+}
+
 // Register prefetch and s_waitcnt: the S new rows of step st+1 are requested at the start of step st and written to LDS
 // at its end.  hipcc counts outstanding vector-memory operations per basic block and merges conservatively at joins, so
 // every branch around a store (row / column guards) between the loads and their use made it wait for vmcnt(0) there --
@@ -481,7 +488,15 @@ __device__ __forceinline__ float row16_max_to_lane15(float e) {
 // float rows of a layer blur (6 dwords per lane instead of 18 floats), turned into luma ONCE per input pixel into a tile
 // that borrows the dead rows of the current ring half, and expanded from there into the ring rows (an even output row /
 // column is a luma row / column exactly, an odd one the 0.5 / 0.5 blend, in the reference's expression order).
-template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1>
+// H8: the horizontal pass gives a lane 8 adjacent outputs (16 lanes per row) instead of 4: it reads (8 + 2R) floats for 8
+// outputs where the 4-output form reads (4 + 2R) for 4 -- at R = 13, 10 float4 LDS reads per 8 outputs instead of 18 -- and
+// the per-output share of its address arithmetic halves.  Lanes 32 B apart would collide on the LDS banks with the row
+// below them in the same ds_read_b128 lane group, so rows at odd ring slots keep every pair of adjacent float4s swapped
+// (float offset ^ 4): a lane still reads its own contiguous floats (in another order), the two rows of a lane group
+// interleave on the banks, and every other access to the ring applies the same XOR.  Measured on 32 x 3840x2160: 2-3.5 %
+// faster for R = 5 ... 10; at R >= 13 its 40 + 8 registers per item no longer fit 128 VGPRs beside the prefetch (spill),
+// so those radii keep 4 outputs per lane.
+template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12)>
 __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                              int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
@@ -493,7 +508,8 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
     static_assert(!SEED || (TLW * TLH <= (S - 2 * R) * LW && !DEC && !ACT), "the luma tile borrows the dead rows of a ring half");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // max|Eh| of (ring row, cell): only with ACT (see RingGeom::EHM_IN_ROW)
-    auto ehm = [&](int slot, int cell) -> float & { return G::EHM_IN_ROW ? lds[slot * LW + cell] : lds[LW * NR + slot * 2 + cell]; };
+    auto x4 = [](int slot) { return H8 ? (slot & 1) << 2 : 0; };                 // XOR on a float offset inside ring row `slot` (see H8)
+    auto ehm = [&](int slot, int cell) -> float & { return G::EHM_IN_ROW ? lds[slot * LW + (cell ^ x4(slot))] : lds[LW * NR + slot * 2 + cell]; };
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware 1-D order (see blur2_kernel): frame, chunk, strip with the strip index fastest
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             const int sx = symm(x0 - RP + lx, w), sy = symm(ybeg + R + u0 + lu, h);
             float v = 0.0f;
             if (sx >= 0 && sy >= 0 && sx < w && sy < h) v = SEED ? seed_sample(px, seed, sx, sy, w, h) : in[(size_t)sy * w + sx];
-            lds[slot * LW + lx] = v;
+            lds[slot * LW + (lx ^ x4(slot))] = v;
         }
     };
     // Row loads of the fast path.  8 lanes per row: lane q of a row takes the float4 columns q + 8 j (j < NPF4) and, when
@@ -538,10 +554,12 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         if (G::REM) rem = load_pair_mirrored(rowp, x0 - RP + 32 * G::NPF4 + 2 * pf_q, w);   // the last 16 halo columns, right of the strip
     };
     auto store_rows = [&](int u_first, int nrows, const f32x4 (&buf)[G::NPF4], const f32x2 &rem) {   // -> ring rows u_first + ...
-        float *rowp = lds + ((u_first + min(pf_row, nrows - 1) + NR) & (NR - 1)) * LW;     // lanes past nrows repeat the last row
+        const int slot = (u_first + min(pf_row, nrows - 1) + NR) & (NR - 1);               // lanes past nrows repeat the last row
+        float *rowp = lds + slot * LW;
+        const int x = x4(slot);
 #pragma unroll
-        for (int j = 0; j < G::NPF4; j++) *reinterpret_cast<f32x4 *>(rowp + 4 * pf_q + 32 * j) = buf[j];
-        if (G::REM) *reinterpret_cast<f32x2 *>(rowp + 32 * G::NPF4 + 2 * pf_q) = rem;
+        for (int j = 0; j < G::NPF4; j++) *reinterpret_cast<f32x4 *>(rowp + ((4 * pf_q + 32 * j) ^ x)) = buf[j];
+        if (G::REM) *reinterpret_cast<f32x2 *>(rowp + ((32 * G::NPF4 + 2 * pf_q) ^ x)) = rem;
     };
 
     // Seed loader (SEED only).  Tile = luma of input rows ilo ... ilo + TLH - 1, columns clo ... clo + TLW - 1 (clamped to the
@@ -570,7 +588,8 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         const float *tm = tile + (jm - ilo) * TLW - clo, *tp = tile + (jp - ilo) * TLW - clo;
         // vertical blend of input column c: fy * L(c, jp) + (1 - fy) * L(c, jm); with fy = 0 that is L(c, jm) exactly
         auto A = [&](int c) { const float cm = tm[c], cp = tp[c]; return odd ? 0.5f * cp + 0.5f * cm : cm; };
-        float *rowp = lds + ((u_first + lr + NR) & (NR - 1)) * LW;
+        const int slot = (u_first + lr + NR) & (NR - 1), x = x4(slot);
+        float *rowp = lds + slot * LW;
 #pragma unroll
         for (int j = 0; j < G::NPF4; j++) {
             const int gx = x0 - RP + 4 * pf_q + 32 * j;
@@ -582,7 +601,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             const float o0 = a0, o1 = 0.5f * a1 + 0.5f * a0, o2 = a1, o3 = 0.5f * a2 + 0.5f * a1;
             f32x4 o;
             o.x = mir ? o3 : o0; o.y = mir ? o2 : o1; o.z = mir ? o1 : o2; o.w = mir ? o0 : o3;
-            *reinterpret_cast<f32x4 *>(rowp + 4 * pf_q + 32 * j) = o;
+            *reinterpret_cast<f32x4 *>(rowp + ((4 * pf_q + 32 * j) ^ x)) = o;
         }
         if (G::REM) {
             const int gx = x0 - RP + 32 * G::NPF4 + 2 * pf_q;
@@ -592,7 +611,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             const float o0 = a0, o1 = 0.5f * a1 + 0.5f * a0;
             f32x2 o;
             o.x = mir ? o1 : o0; o.y = mir ? o0 : o1;
-            *reinterpret_cast<f32x2 *>(rowp + 32 * G::NPF4 + 2 * pf_q) = o;
+            *reinterpret_cast<f32x2 *>(rowp + ((32 * G::NPF4 + 2 * pf_q) ^ x)) = o;
         }
     };
 
@@ -662,6 +681,40 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         stamp(0);
         // horizontal pass, in place (first step: the S + 2R prologue rows; later steps: the S new rows)
         const int hb = st == 0 ? -2 * R : st * S, hn = st == 0 ? S + 2 * R : S;
+        if constexpr (H8) {
+#pragma unroll 1
+            for (int item = tid; item < ((DBG & 8) ? 0 : hn * 16); item += G::NTHR) {
+                const int slot = (hb + (item >> 4) + NR) & (NR - 1), c8 = (item & 15) * 8;
+                float *rowp = lds + slot * LW + c8;
+                // logical float4 m of this lane's segment sits at float4 m ^ (slot & 1): even m at +D, odd m at -D, D = 4 (slot & 1)
+                const int D = x4(slot);
+                constexpr int M0 = (RP - R) / 4, M1 = (RP + R + 7) / 4 + 1;
+                float v[4 * (M1 - M0)];
+                const lds_cv_f32x4 *re = (const lds_cv_f32x4 *)(rowp + D), *ro = (const lds_cv_f32x4 *)(rowp - D);
+#pragma unroll
+                for (int m = M0; m < M1; m++) {
+                    const f32x4 tv = (m & 1) ? ro[m] : re[m];
+                    v[4 * (m - M0) + 0] = tv.x; v[4 * (m - M0) + 1] = tv.y; v[4 * (m - M0) + 2] = tv.z; v[4 * (m - M0) + 3] = tv.w;
+                }
+                float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < G::NT; i++) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc[k] = fmaf(tw(i), v[(RP - R - 4 * M0) + k + i], acc[k]);
+                }
+                static_assert((RP / 4) % 2 == 0, "the first output float4 of a lane must be an even one");
+                *reinterpret_cast<float4 *>(rowp + RP + D) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4 *>(rowp + RP + 4 - D) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                if (ACT) {                                  // max |hb - raw| over this row's 64-column cell (8 lanes x 8 columns)
+                    constexpr int C = RP - 4 * M0;
+                    float e = fabsf(acc[0] - v[C + 0]);
+#pragma unroll
+                    for (int k = 1; k < 8; k++) e = fmaxf(e, fabsf(acc[k] - v[C + k]));
+                    e = row8_max_to_lane7(e);
+                    if ((tid & 7) == 7) ehm(slot, (tid >> 3) & 1) = e;
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int item = tid; item < ((DBG & 8) ? 0 : hn * 32); item += G::NTHR) {
             const int slot = (hb + (item >> 5) + NR) & (NR - 1), c4 = (item & 31) * 4;
@@ -688,6 +741,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                 if ((tid & 15) == 15) ehm(slot, (tid >> 4) & 1) = e;
             }
         }
+        }
         stamp(1);
         lds_barrier();                                       // B2: blurred rows complete
         stamp(2);
@@ -695,7 +749,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         // vertical pass: wavefront wv owns output rows wv RB ... wv RB + RB - 1 of the step, a lane 2 columns
         {
             const int u0 = st * S + wv * RB - 2 * R;         // first window row (wave-uniform)
-            const float *colp = lds + RP + 2 * lane;
+            const float *colp = lds + RP + 2 * lane, *colx = lds + ((RP + 2 * lane) ^ (H8 ? 4 : 0));   // even / odd ring slots (u0 is even: slot parity = k & 1)
             f32x2 cen[ACT ? RB : 1];                        // hb under each output (the centre tap's operand), for the activity bound
             f32x2 acc[RB];
 #pragma unroll
@@ -703,7 +757,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
 #pragma unroll
             for (int k = 0; k < ((DBG & 16) ? 0 : RB + 2 * R); k++) {
                 const int slot = (u0 + k + NR) & (NR - 1);
-                const f32x2 v = *(const lds_cv_f32x2 *)(colp + slot * LW);
+                const f32x2 v = *(const lds_cv_f32x2 *)(((k & 1) ? colx : colp) + slot * LW);
 #pragma unroll
                 for (int rr = 0; rr < RB; rr++) {
                     const int i = k - rr;

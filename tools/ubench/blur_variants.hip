@@ -90,6 +90,16 @@ static void bench_R(Ctx &c, float rho) {
             const char *nm[8] = {"issue", "H", "B2wait", "V", "stores", "B3wait", "vmwait+ldsw", "B1wait"}; \
             printf("      stamps (cycles per wave-step, share):"); for (int k = 0; k < 8; k++) printf(" %s %.0f (%.0f%%)", nm[k], sum[k] / ((double)tx * c.nf * ((c.h + S_ - 1) / S_) * 4) , 100.0 * sum[k] / tot); printf("\n"); } }
     VR(32, 128, 4, 0) VR(32, 256, 4, 0)
+#define VRH4(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " H4 (4 outputs per lane, no swizzle)", c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, false>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
+    VRH4(32, 256, 4)
+#define VRX(S_, CHR_, MINW_, H8_) { using G = RingGeom<R, S_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, H8_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
+    VRX(32, 256, 3, true) VRX(32, 256, 3, false)
     // with the extrema activity flags (ACT) as layers 2 ... nspo+1 of the pipeline write them
 #define VRA(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
