@@ -735,3 +735,29 @@ def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the contract's keys, the roofline object (with the PMC traffic figure and the
+    per-launch-shape table) and, with SIFTMI_FORCE_GATHER under torchrun, the exchange fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Mpixels/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - 64 * 1920 * 1080 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] and r["traffic"] > r["algorithmic_bytes_per_launch_avg"]
+    shapes = r["by_launch_shape"]
+    assert len(shapes) == 20 and shapes["o0_l5"]["kernel"].startswith("blur_ring_kernel<13") and shapes["o0_l3"]["decimating"]
+    assert "workload" in d["config"] and "model" not in d["config"]
