@@ -41,6 +41,6 @@ def run(name, w, h, n_oct, frames, lockstep, reps, gray=False, kp_per_frame=3276
 if __name__ == "__main__":
     run("configs[0] shape on the GPU: 640x480 gray, 3 octaves, single frame", 640, 480, 3, 1, 1, 50, gray=True)
     run("configs[1]: single 1920x1080 frame, 4 octaves", 1920, 1080, 4, 1, 1, 50)
-    run("configs[2]: 64 x 1920x1080, 4 octaves (bench.py value)", 1920, 1080, 4, 64, 32, 5)
+    run("configs[2]: 64 x 1920x1080, 4 octaves (bench.py value)", 1920, 1080, 4, 64, 64, 5)
     if "--tile" in sys.argv:
         run("configs[4]: single 8192x8192 tile, 6 octaves", 8192, 8192, 6, 1, 1, 3, kp_per_frame=1 << 20, desc_per_frame=3 << 19)
