@@ -26,6 +26,12 @@ namespace siftmi {
 
 #define SIFTMI_PI_F 3.14159265358979323846264338327950288f
 
+#ifndef SIFTMI_DESC_NCOPY
+#define SIFTMI_DESC_NCOPY 4                                // private histogram copies per wavefront in descriptor_kernel (tuning experiments override it)
+#endif
+#ifndef SIFTMI_ORI_NCOPY
+#define SIFTMI_ORI_NCOPY 4                                 // same for the 36-bin histogram of orientation_kernel
+#endif
 constexpr int MAX_OCT = 16;
 constexpr int ORI_BINS = 36;
 constexpr int DESC_N = 128;
@@ -532,34 +538,97 @@ __global__ __launch_bounds__(256) void kp_row_rank_kernel(PyramidDesc P, const K
 // (bit-reproducible) and closer to the real-number sum than the reference's sequential f32 sum; the
 // difference to the oracle is its own f32 rounding (~1e-6 relative), inside the stated tolerances.
 constexpr float FIX40 = 1099511627776.0f;             // 2^40
-__device__ __forceinline__ unsigned long long to_fix40(float c) {
-    const float x = c * FIX40;                                            // exact (power of two)
+#ifndef SIFTMI_LEAN_ATAN
+#define SIFTMI_LEAN_ATAN 1
+#endif
+// x = c * 2^40 (exact scaling) to a 64-bit integer, truncating; there is no f32 -> u64 instruction, so two 32-bit
+// conversions.  (Measured and not kept: adding 2^52 in double and masking the mantissa -- 3 VALU instead of 5, but the
+// f64 convert / add issue slower: describe 9.76 against 9.62 ms per dense step.)
+__device__ __forceinline__ unsigned long long fix_of_scaled(float x) {
     const unsigned hi = (unsigned)(x * 2.3283064365386963e-10f);          // trunc(x / 2^32), < 2^18
     const float rem = fmaf(-(float)hi, 4294967296.0f, x);                 // exact
-    const unsigned lo = (unsigned)rem;
-    return ((unsigned long long)hi << 32) | lo;
+    return ((unsigned long long)hi << 32) | (unsigned)rem;
 }
+__device__ __forceinline__ unsigned long long to_fix40(float c) { return fix_of_scaled(c * FIX40); }
 __device__ __forceinline__ float from_fix40(unsigned long long v) { return (float)v * (1.0f / FIX40); }
+// to_fix40(p * value) with the power-of-two scaling hoisted out of the per-corner code: v40 = value * 2^40 is exact, so
+// p * v40 carries the significand of p * value -- the same 64-bit result, one multiply fewer per contribution.
+__device__ __forceinline__ unsigned long long fix40_product(float p, float v40) { return fix_of_scaled(p * v40); }
+
+// atan2(y, x) of finite arguments for the sample loops (their VALU count is the limit of the orientation and descriptor
+// kernels; the library atan2f is 38 of it, with exponent juggling for a correctly scaled quotient and inf / nan cases that
+// cannot occur here).  Octant reduction, quotient by v_rcp_f32 (1 ulp), odd degree-17 polynomial fitted by
+// tools/fit_atan.py: 2.4 ulp / 2.9e-7 rad worst case over 2M random arguments.  An angle error of that size moves 1e-7 of
+// a sample's weight between neighbouring bins of the descriptor, and one sample in ~3e5 to the neighbouring orientation
+// bin -- two orders below the differences the f32 sums of the reference carry anyway.  atan2_lean(0, 0) = 0 as atan2f.
+__device__ __forceinline__ float atan2_lean(float y, float x) {
+#if SIFTMI_LEAN_ATAN
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
+    const float s = t * t;
+    float q = 2.622172935e-03f;
+    q = fmaf(q, s, -1.513224095e-02f);
+    q = fmaf(q, s, 4.112136364e-02f);
+    q = fmaf(q, s, -7.366662472e-02f);
+    q = fmaf(q, s, 1.057391018e-01f);
+    q = fmaf(q, s, -1.418596953e-01f);
+    q = fmaf(q, s, 1.999039650e-01f);
+    q = fmaf(q, s, -3.333298564e-01f);
+    float r = fmaf(t, s * q, t);
+    r = ay > ax ? 1.57079632679489662f - r : r;
+    r = x < 0.0f ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
+#else
+    return atan2f(y, x);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // Gradient on demand: SIFTGradient.metal:15-39 (atan2(tx, ty) -- argument order as in the
 // reference -- and |grad| of central differences, mirror edges); outside the image -> (0, 0).
+//
+// The layer is addressed through a buffer resource: one keypoint per wavefront, so the layer base is wave-uniform and sits
+// in SGPRs; a sample then needs one 32-bit byte offset (2 VALU) instead of four 64-bit addresses (the orientation and
+// descriptor kernels are VALU-bound: PMC, dense frames).  Interior samples -- all but a handful -- take the four loads at
+// constant offsets from it; samples on the image edge take the mirrored path.
+struct LayerView {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const float *g;
+    int w, h, pitch;                                                   // pitch = 4 w bytes
+};
+__device__ __forceinline__ LayerView layer_view(const float *g, int w, int h) {
+    const unsigned long long a = (unsigned long long)g;
+    const unsigned long long u = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    LayerView v;
+    v.g = (const float *)u; v.w = w; v.h = h; v.pitch = 4 * w;
+    v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, 4 * w * h, 0x00020000);   // raw 32-bit elements, range-checked
+    return v;
+}
+__device__ __forceinline__ float layer_ld(const LayerView &v, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(v.rsrc, byte_off, 0, 0));
+}
 template <bool FAST_SQRT = false>
-__device__ __forceinline__ void gradient_at(const float *g, int w, int h, int gx, int gy, float &theta, float &mag) {
-    if (gx < 0 || gy < 0 || gx >= w || gy >= h) { theta = 0.0f; mag = 0.0f; return; }
-    float tx, ty;
-    if (gx >= 1 && gy >= 1 && gx < w - 1 && gy < h - 1) {          // interior: no mirror
-        const float *p = g + (size_t)gy * w + gx;
-        tx = (p[1] - p[-1]) * 0.5f;
-        ty = (p[w] - p[-w]) * 0.5f;
-    } else {
+__device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, float &theta, float &mag) {
+    float tx = 0.0f, ty = 0.0f;
+    if ((unsigned)(gx - 1) < (unsigned)(v.w - 2) && (unsigned)(gy - 1) < (unsigned)(v.h - 2)) {          // interior: no mirror
+        const int c = gy * v.pitch + (gx << 2);
+        tx = (layer_ld(v, c + 4) - layer_ld(v, c - 4)) * 0.5f;
+        ty = (layer_ld(v, c + v.pitch) - layer_ld(v, c - v.pitch)) * 0.5f;
+    } else if (gx >= 0 && gy >= 0 && gx < v.w && gy < v.h) {
+        const int w = v.w, h = v.h;
+        const float *g = v.g;
         const int px = symm(gx + 1, w), mx = symm(gx - 1, w);
         const int py = symm(gy + 1, h), my = symm(gy - 1, h);
         auto rd = [&](int x, int y) -> float { return (x < 0 || y < 0 || x >= w || y >= h) ? 0.0f : g[(size_t)y * w + x]; };
         tx = (rd(px, gy) - rd(mx, gy)) * 0.5f;
         ty = (rd(gx, py) - rd(gx, my)) * 0.5f;
+    } else {                                                            // outside the image -> (0, 0)
+        theta = 0.0f; mag = 0.0f;
+        return;
     }
-    theta = atan2f(tx, ty);
+    theta = atan2_lean(tx, ty);
     mag = FAST_SQRT ? __builtin_amdgcn_sqrtf(tx * tx + ty * ty) : sqrtf(tx * tx + ty * ty);
 }
 
@@ -571,9 +640,14 @@ __device__ __forceinline__ void gradient_at(const float *g, int w, int h, int gx
 __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectParams prm,
                                                          const KeypointRec *__restrict__ kps, const int32_t *__restrict__ kp_count,
                                                          int32_t *__restrict__ ori_count, float *__restrict__ ori_angles) {
-    __shared__ unsigned long long hist_all[4][ORI_BINS + 4];
+    // 4 private copies of the 36-bin histogram per wave (copy = lane % 4), 37 u64 apart so that the copies of a bin sit on
+    // different LDS banks: neighbouring lanes (neighbouring pixels) mostly share a bin, and same-address lanes of one
+    // ds_add_u64 serialise
+    constexpr int OCOPY = SIFTMI_ORI_NCOPY, OSTRIDE = ORI_BINS + 1;
+    __shared__ unsigned long long hist_all[4][OCOPY * OSTRIDE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long *hist = hist_all[wv];
+    unsigned long long *hist0 = hist_all[wv];
+    unsigned long long *hist = hist0 + (lane & (OCOPY - 1)) * OSTRIDE;
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
     const int w = P.w[o], h = P.h[o];
@@ -594,8 +668,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
             continue;
         }
         const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // :333-334 Int32 truncation
-        const float *g = layer_ptr(P, frame, o, kp.scale);
-        if (lane < ORI_BINS) hist[lane] = 0ull;
+        const LayerView g = layer_view(layer_ptr(P, frame, o, kp.scale), w, h);
+        for (int c = lane; c < OCOPY * OSTRIDE; c += 64) hist0[c] = 0ull;
         __builtin_amdgcn_wave_barrier();
         {   // SIFTOrientation.metal:87-136
             const int x = (int)roundf((float)absoluteX / delta);
@@ -607,14 +681,15 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
             const float inv_sigma = 1.0f / sigma, neg_inv_den = -1.0f / exponentDenominator;
             const int r = (int)ceilf(3.0f * lambda * sigma);
             const int side = 2 * r + 1, total = side * side;
+            const float inv_side = 1.0f / (float)side;                 // idx / side below: idx + 0.5 keeps the quotient >= 0.5 / side off every integer, far more than the float error at idx < 2^20
             for (int idx = lane; idx < total; idx += 64) {
-                const int jj = idx / side, ii = idx - jj * side;
+                const int jj = (int)(((float)idx + 0.5f) * inv_side), ii = idx - jj * side;
                 const int j = jj - r, i = ii - r;
                 const float u = (float)i * inv_sigma, v = (float)j * inv_sigma;
                 const float r2 = u * u + v * v;
                 const float wgt = __expf(r2 * neg_inv_den);
                 float orientation, magnitude;
-                gradient_at<true>(g, w, h, x + i, y + j, orientation, magnitude);
+                gradient_at<true>(g, x + i, y + j, orientation, magnitude);
                 const float t = orientation / (2.0f * SIFTMI_PI_F);
                 int bin = (int)roundf(t * (float)ORI_BINS);
                 if (bin < 0) bin += ORI_BINS;
@@ -626,7 +701,10 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         const int li = lane < ORI_BINS ? lane : 0;
-        float hv = from_fix40(hist[li]);
+        unsigned long long hsum = hist0[li];
+#pragma unroll
+        for (int c = 1; c < OCOPY; c++) hsum += hist0[c * OSTRIDE + li];
+        float hv = from_fix40(hsum);
         const int lm = (li + ORI_BINS - 1) % ORI_BINS, lp = (li + 1) % ORI_BINS;
         for (int it = 0; it < prm.ori_smoothing; it++) {               // :67-84
             const float h0 = __shfl(hv, lm), h2 = __shfl(hv, lp);
@@ -703,8 +781,8 @@ __global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P,
 // per sample, v_exp_f32 (__expf) and v_sqrt_f32 -- 1-2 ulp on quantities that only weight a sample, against a stated
 // descriptor tolerance of 1e-4 (L2).  Measured against the oracle (IEEE division, glibc expf / sqrtf) on 17.6 k dense
 // descriptors: max L2 5.1e-7 with either form, 9 instead of 5 of 2.25 M quantised bins differ by 1
-// (tools/desc_margin.py); the sample loop is VALU-bound and this removes ~50 of its ~330 instructions.  atan2f stays
-// the library's: the orientation bin it feeds is interpolated, and the orientation stage bins to the nearest integer.
+// (tools/desc_margin.py); the sample loop is VALU-bound and this removes ~50 of its ~330 instructions.  The angle comes
+// from atan2_lean (above; 2.4 ulp): with it 11 of the 2.25 M bins differ, max L2 5.2e-7.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -716,24 +794,28 @@ __device__ __forceinline__ float wave_sum(float v) {
 // wavefront slots, and a descriptor's ~3000 samples walked by 64 lanes take 60-100 us of dependent loads and LDS atomics;
 // four waves cut that to a quarter.  Same samples into the same u64 fixed-point bins, so the result is bit-identical.
 template <bool COOP>
-__global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectParams prm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
                                                         float *__restrict__ desc_f32 /* may be null */) {
     // NCOPY private copies of the 4x4x8 histogram per wave (copy = lane % NCOPY): neighbouring lanes
     // take neighbouring samples, which mostly fall into the same cell and bin, and same-address lanes
     // of one ds_add_u64 serialise (6 cycles distinct, 26 at 4 lanes per address).  u64 fixed point: see to_fix40.
-    constexpr int NCOPY = 4;
+    // Measured and not kept: padding the copies to 129 u64 apart (the PMC run on dense frames shows 72 % of this kernel's LDS
+    // cycles as bank conflicts) and 8 copies instead of 4 -- describe went 10.85 -> 11.1 / 12.7 ms per dense step: the
+    // conflicts counted are the atomics' own same-bank serialisation across the 8 orientation bins of one cell, which the
+    // pitch of the copies does not change.
+    constexpr int NCOPY = SIFTMI_DESC_NCOPY, CSTRIDE = DESC_N;
     constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
-    __shared__ unsigned long long patch_all[4][NCOPY][DESC_N];
+    __shared__ unsigned long long patch_all[4][NCOPY * CSTRIDE];
     __shared__ int col_start_all[4][MAXCOL + 1];
     __shared__ short col_lo_all[4][MAXCOL];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hw_ = COOP ? 0 : wv;                          // whose histogram copies: the workgroup's (COOP) or this wave's
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
     const int lidx = COOP ? (int)threadIdx.x : lane;
-    unsigned long long *patch = patch_all[hw_][lane & (NCOPY - 1)];
-    unsigned long long *patch0 = patch_all[hw_][0];
+    unsigned long long *patch0 = patch_all[hw_];
+    unsigned long long *patch = patch0 + (lane & (NCOPY - 1)) * CSTRIDE;
     int *col_start = col_start_all[wv];
     short *col_lo = col_lo_all[wv];
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
@@ -747,7 +829,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
         const KeypointRec kp = kps[kbase + in.keypoint];
         const float theta = in.theta;
         const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // SIFTOctave.swift:417-418
-        const float *g = layer_ptr(P, frame, o, kp.scale);
+        const LayerView g = layer_view(layer_ptr(P, frame, o, kp.scale), w, h);
         const float px = (float)absoluteX / delta, py = (float)absoluteY / delta;   // metal :140-141
         const int d = 4, bins = 8;
         const float tau = 2.0f * SIFTMI_PI_F;
@@ -764,10 +846,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
 
         if (COOP) {
             __syncthreads();                                                          // wave 0 is done reading the previous descriptor's bins
-            for (int c = threadIdx.x; c < NCOPY * DESC_N; c += 256) patch0[c] = 0ull;
+            for (int c = threadIdx.x; c < NCOPY * CSTRIDE; c += 256) patch0[c] = 0ull;
         } else {
-#pragma unroll
-            for (int c = 0; c < NCOPY * DESC_N / 64; c++) patch0[c * 64 + lane] = 0ull;   // all copies (contiguous)
+            for (int c = lane; c < NCOPY * CSTRIDE; c += 64) patch0[c] = 0ull;             // all copies (contiguous)
         }
         const int side = 2 * radius + 1;
 
@@ -842,9 +923,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
             // every trilinear corner of this sample lies outside the 4x4 grid (addValue :66-68 drops
             // all 8 contributions): nothing to add
             if (bx <= -1.0f || bx >= 4.0f || by <= -1.0f || by >= 4.0f) continue;
-            const float fx = truncf(px + (float)j), fy = truncf(py + (float)i);   // ushort2(px + j, py + i)
+            const float fx = px + (float)j, fy = py + (float)i;                    // ushort2(px + j, py + i): truncation; (-1, 0) -> 0
             float gth = 0.0f, gm = 0.0f;
-            if (fx >= 0.0f && fy >= 0.0f && fx < (float)w && fy < (float)h) gradient_at<true>(g, w, h, (int)fx, (int)fy, gth, gm);
+            if (fx > -1.0f && fy > -1.0f) gradient_at<true>(g, (int)fx, (int)fy, gth, gm);   // (int) of a huge float is >= w: outside
             float orientation = gth - theta;
             while (orientation < 0.0f) orientation += tau;
             while (orientation >= tau) orientation -= tau;
@@ -855,32 +936,33 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyramidDesc P, DetectPa
             {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
                 // and bin wrap (:59-79); here one test per cell corner, the two orientation bins wrapped once (bin lies in
                 // [0, 8]: floor / ceil can reach 8, never go negative).  Same products in the same order.
+                // The "upper" corner is floor + 1 here, not ceil: they differ only when the coordinate is an integer, and then
+                // the upper corner's weight is exactly 0 -- it adds 0 whichever cell or bin it names.
                 const float flx = floorf(bx), fly = floorf(by), flb = floorf(bin);
                 const int cax = (int)flx, cay = (int)fly;
-                const int cbx = (int)ceilf(bx), ccy = (int)ceilf(by);
-                int ba = (int)flb, bb = (int)ceilf(bin);
-                if (ba >= 8) ba -= 8;
-                if (bb >= 8) bb -= 8;
+                const int cbx = cax + 1, ccy = cay + 1;
+                const int ba = (int)flb & 7, bb = ((int)flb + 1) & 7;
                 const float iMax = bx - flx, iMin = 1.0f - iMax;
                 const float jMax = by - fly, jMin = 1.0f - jMax;
                 const float bMax = bin - flb, bMin = 1.0f - bMax;
                 const bool xa = (unsigned)cax < 4u, xb = (unsigned)cbx < 4u, ya = (unsigned)cay < 4u, yb = (unsigned)ccy < 4u;
+                const float v40 = value * FIX40;
                 unsigned long long *pa = patch + ba, *pb = patch + bb;
                 if (xa && ya) { const float wxy = iMin * jMin; const int c = cay * 32 + cax * 8;
-                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
+                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
                 if (xb && ya) { const float wxy = iMax * jMin; const int c = cay * 32 + cbx * 8;
-                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
+                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
                 if (xb && yb) { const float wxy = iMax * jMax; const int c = ccy * 32 + cbx * 8;
-                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
+                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
                 if (xa && yb) { const float wxy = iMin * jMax; const int c = ccy * 32 + cax * 8;
-                                atomicAdd(pa + c, to_fix40((wxy * bMin) * value)); atomicAdd(pb + c, to_fix40((wxy * bMax) * value)); }
+                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
             }
         }
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
         __threadfence_block();
         unsigned long long a0 = patch0[lane], a1 = patch0[64 + lane];
 #pragma unroll
-        for (int c = 1; c < NCOPY; c++) { a0 += patch0[c * DESC_N + lane]; a1 += patch0[c * DESC_N + 64 + lane]; }
+        for (int c = 1; c < NCOPY; c++) { a0 += patch0[c * CSTRIDE + lane]; a1 += patch0[c * CSTRIDE + 64 + lane]; }
         float f0 = from_fix40(a0), f1 = from_fix40(a1);
         {   // normalise -> clamp 0.2 -> normalise (:15-39, :224-227)
             float dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));

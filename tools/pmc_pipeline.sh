@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: tools/pmc_pipeline.sh <kernel-name substring> [frames] [batch]
+# usage: tools/pmc_pipeline.sh <kernel-name substring> [frames] [batch] [dense]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-K=$1; F=${2:-16}; B=${3:-8}
+R=${GRAFT_REPO_ROOT:-$PWD}
+K=$1; F=${2:-16}; B=${3:-8}; KIND=${4:-}
 OUT=$R/gpurun_out/pmc_pipe
 rm -rf $OUT; mkdir -p $OUT
 i=0
@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAVES" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/prof_pipeline.py $F $B 1 > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/prof_pipeline.py $F $B 1 $KIND > $OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
