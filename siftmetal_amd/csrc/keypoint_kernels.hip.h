@@ -33,6 +33,7 @@ namespace siftmi {
 #define SIFTMI_ORI_NCOPY 4                                 // same for the 36-bin histogram of orientation_kernel
 #endif
 constexpr int MAX_OCT = 16;
+constexpr int MAX_NG = 11;            // Gaussian layers per octave = nspo + 3, nspo <= 8
 constexpr int ORI_BINS = 36;
 constexpr int DESC_N = 128;
 
@@ -52,7 +53,7 @@ struct PyramidDesc {
     int32_t w[MAX_OCT], h[MAX_OCT];
     float delta[MAX_OCT];
     float sigma0[MAX_OCT], sigma1[MAX_OCT];   // sigmas[0], sigmas[1] of the octave (SIFTOctave.swift:211)
-    float sigmas[MAX_OCT][8];          // sigmas[s], s < nspo+3 <= 8
+    float sigmas[MAX_OCT][MAX_NG];     // sigmas[s], s < nspo+3 <= MAX_NG
     int32_t n_octaves, nspo;
     int32_t cap_ext[MAX_OCT], cap_kp[MAX_OCT], cap_desc[MAX_OCT];
     size_t ext_off[MAX_OCT], kp_off[MAX_OCT], desc_off[MAX_OCT];   // element offsets of the octave's segment inside a frame's segment

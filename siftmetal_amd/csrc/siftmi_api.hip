@@ -86,9 +86,9 @@ struct siftmi_ctx {
     // schedule
     int ow[MAX_OCT], oh[MAX_OCT];
     float odelta[MAX_OCT];
-    float osigma[MAX_OCT][8];
-    int seed_taps = 0, taps[8];
-    TapWeights seed_w, layer_w[8];
+    float osigma[MAX_OCT][MAX_NG];
+    int seed_taps = 0, taps[MAX_NG];
+    TapWeights seed_w, layer_w[MAX_NG];
     // device memory
     float *d_gauss = nullptr;
     size_t frame_stride = 0;                  // floats
@@ -181,8 +181,8 @@ struct siftmi_ctx {
     std::vector<EventPair> pending, pool;
     double t_ms[SIFTMI_T_COUNT];
     int64_t t_launches[SIFTMI_T_COUNT];
-    double t_blur_ms[MAX_OCT][8];             // the SIFTMI_T_BLUR time split by (octave, layer): one kernel name and grid each
-    int64_t t_blur_launches[MAX_OCT][8];
+    double t_blur_ms[MAX_OCT][MAX_NG];             // the SIFTMI_T_BLUR time split by (octave, layer): one kernel name and grid each
+    int64_t t_blur_launches[MAX_OCT][MAX_NG];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -275,7 +275,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
         return set_error(SIFTMI_E_BADARG, "input size %dx%d out of range [1, 32768]", cfg->width, cfg->height);
     if (cfg->n_octaves < 1 || cfg->n_octaves > SIFTMI_MAX_OCTAVES)
         return set_error(SIFTMI_E_BADARG, "n_octaves %d out of range [1, %d]", cfg->n_octaves, SIFTMI_MAX_OCTAVES);
-    if (cfg->nspo < 1 || cfg->nspo > 5) return set_error(SIFTMI_E_BADARG, "nspo %d out of range [1, 5]", cfg->nspo);
+    if (cfg->nspo < 1 || cfg->nspo + 3 > MAX_NG) return set_error(SIFTMI_E_BADARG, "nspo %d out of range [1, %d]", cfg->nspo, MAX_NG - 3);
     if (cfg->delta_min != 0.5f) return set_error(SIFTMI_E_BADARG, "delta_min must be 0.5 (2x seed image)");
     if (cfg->max_batch < 1 || cfg->max_batch > 4096) return set_error(SIFTMI_E_BADARG, "max_batch %d out of range", cfg->max_batch);
     int ndev = 0;
@@ -449,7 +449,7 @@ static void t_collect(siftmi_ctx *c) {
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             c->t_ms[ep.stage] += ms;
             c->t_launches[ep.stage] += 1;
-            if (ep.stage == SIFTMI_T_BLUR && ep.sub >= 0) { c->t_blur_ms[ep.sub >> 3][ep.sub & 7] += ms; c->t_blur_launches[ep.sub >> 3][ep.sub & 7] += 1; }
+            if (ep.stage == SIFTMI_T_BLUR && ep.sub >= 0) { c->t_blur_ms[ep.sub >> 4][ep.sub & 15] += ms; c->t_blur_launches[ep.sub >> 4][ep.sub & 15] += 1; }
         }
         c->pool.push_back(ep);
     }
@@ -591,7 +591,10 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
         case 2: LAUNCH_EXT(2); break;
         case 3: LAUNCH_EXT(3); break;
         case 4: LAUNCH_EXT(4); break;
-        default: LAUNCH_EXT(5); break;
+        case 5: LAUNCH_EXT(5); break;
+        case 6: LAUNCH_EXT(6); break;
+        case 7: LAUNCH_EXT(7); break;
+        default: LAUNCH_EXT(8); break;
     }
 #undef LAUNCH_EXT
     HIP_TRY(hipGetLastError());
@@ -643,7 +646,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
             if (c->act_valid[o] && s >= 2 && s <= c->nspo + 1)
                 act = Activity{c->d_act + c->act_off[o] + (size_t)(s - 2) * c->oh[o] * c->act_ncell[o], c->act_frame, c->act_ncell[o],
                                c->prm.dog_threshold * 0.8f};
-            t_begin(c, SIFTMI_T_BLUR, o * 8 + s);
+            t_begin(c, SIFTMI_T_BLUR, o * 16 + s);
             HIP_TRY((launch_blur<false>(c, cur, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
                                         nf, c->layer_w[s - 1], none, dec, act)));
             t_end(c);

@@ -35,6 +35,7 @@ CASES = [
     ("tiny", (40, 36), 2, 3),
     ("nspo4", (256, 192), 3, 4),            # other scales-per-octave: different tap counts / layer counts
     ("nspo5", (200, 150), 2, 5),
+    ("nspo8", (232, 168), 2, 8),            # the most layers the kernels take (11 Gaussian / 10 DoG per octave), 5-tap first layer
     ("tall", (130, 700), 4, 3),             # marching kernel: several steps per strip, ragged last step
 ]
 
