@@ -131,12 +131,14 @@ def timed_steps(step, barrier, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "64")), help="frames processed in lock-step per launch")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (cycled to fill the batch)")
     ap.add_argument("--march-min-blocks", type=int, default=0, help="siftmi_config.blur_march_min_blocks (0 = library default)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=(1, 2),
+                    help="steps in flight: 2 alternates consecutive steps between two contexts (two pyramids) on two streams")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip single_frame / host_io / dense")
@@ -189,7 +191,10 @@ def main():
     d_frames = torch.from_numpy(frames_np).to(dev)
     tune = {"blur_march_min_blocks": args.march_min_blocks} if args.march_min_blocks > 0 else {}
     eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
-    runner = smstream.FrameStream(eng, F, device=dev, world_size=world, overlap_gather=use_dist)
+    # the timed stream: consecutive steps alternate between two contexts, so that step k+1's HBM-bound dense stages run under
+    # step k's VALU-bound keypoint stages; `plain` (one context, one step at a time) is what the per-kernel measurements use
+    runner = smstream.FrameStream(eng, F, device=dev, world_size=world, overlap_gather=use_dist, pipeline=args.pipeline)
+    plain = smstream.FrameStream(eng, F, device=dev) if args.pipeline > 1 else runner
 
     def barrier():
         if world > 1:
@@ -205,7 +210,7 @@ def main():
     step()
     barrier()
     first = runner.results_host()
-    if use_dist:                     # both result sets' launch sequences captured (second sighting each) before anything is timed
+    if use_dist or args.pipeline > 1:   # both contexts' / result sets' launch sequences captured (second sighting each) before anything is timed
         for _ in range(4):
             step()
         barrier()
@@ -239,17 +244,26 @@ def main():
                                   "detect+describe, frames and results resident in HBM%s" %
                                   (F, N_OCT, NSPO, ", RCCL all-gather of descriptors" if world > 1 else ""),
                       "frames_per_gpu": F, "lockstep_batch": eng.max_batch, "parallelism": "frame-per-GPU x%d" % world,
+                      "steps_in_flight": args.pipeline,
+                      "pipelining": ("consecutive steps alternate between two contexts (two pyramids, two streams): a step's HBM-bound dense "
+                                     "stages run under the previous step's VALU-bound keypoint stages; every step is computed in full, the "
+                                     "timed region ends with a device synchronisation") if args.pipeline > 1 else None,
                       "rccl_ranks": dist.get_world_size() if use_dist else 1,
                       "all_gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4),
                       "all_gather": "side stream, double-buffered results: step k's exchange runs under step k+1's kernels" if use_dist else None,
                       "keypoints_per_step_rank0": res["n_keypoints"], "descriptors_per_step_rank0": res["n_descriptors"]}}
 
+    if rank == 0 and args.pipeline > 1:
+        # the same K steps one at a time on one context: what the pipelining buys
+        dt1 = timed_steps(lambda: plain.run(d_frames), torch.cuda.synchronize, args.steps, 3)
+        out["config"]["ms_per_step_one_in_flight"] = round(dt1 / args.steps * 1e3, 4)
+        log("one step in flight: %.3f ms/step" % (dt1 / args.steps * 1e3))
     if rank == 0 and not args.no_roofline:
         # second, identical pass with per-launch hipEvents on the launch stream
         eng.enable_timings(True)
         eng.reset_timings()
         for _ in range(args.steps):
-            runner.run(d_frames)
+            plain.run(d_frames)
         torch.cuda.synchronize()
         tm = eng.timings()
         eng.enable_timings(False)
@@ -299,7 +313,7 @@ def main():
                            "launches": blur_n, "avg_launch_ms": round(blur_ms / max(blur_n, 1), 5),
                            "algorithmic_bytes_per_launch_avg": int(total_bytes / max(blur_n, 1)),
                            "octave0_GBps_by_layer": per_layer, "by_launch_shape": shapes, "stage_ms_per_step": stage_ms,
-                           "measured_in": "second identical pass of K steps, hipEvents around every launch on the launch stream"}
+                           "measured_in": "second identical pass of K steps on one context, one step at a time, hipEvents around every launch on the launch stream"}
     if rank == 0 and not args.no_extras:
         # BASELINE configs[1]: ONE 1920x1080 frame per call (lock-step batch 1, hipGraph replay), frame in HBM
         e1 = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=1)
@@ -343,7 +357,7 @@ def main():
         runner.run(d_dense)
         torch.cuda.synchronize()
         dres = runner.results_host()
-        dt_d = timed_steps(lambda: runner.run(d_dense), torch.cuda.synchronize, args.steps, 1)
+        dt_d = timed_steps(lambda: runner.run(d_dense), torch.cuda.synchronize, args.steps, 4)   # warm-up: both contexts capture this input's launch sequence
         ms_d = dt_d / args.steps * 1e3
         out["config"]["dense"] = {"workload": "%d x 1920x1080 mirror-tiled butterfly frames (SURVEY.md 8d dense variant), resident in HBM" % F,
                                   "ms_per_step": round(ms_d, 4), "Mpixels_per_s": round(F * W * H / ms_d / 1e3, 1),
@@ -353,7 +367,7 @@ def main():
             eng.enable_timings(True)
             eng.reset_timings()
             for _ in range(args.steps):
-                runner.run(d_dense)
+                plain.run(d_dense)
             torch.cuda.synchronize()
             out["config"]["dense"]["stage_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in eng.timings().items()}
             eng.enable_timings(False)

@@ -144,6 +144,20 @@ class Engine:
         self.n_octaves, self.nspo, self.max_batch = self.cfg.n_octaves, self.cfg.nspo, self.cfg.max_batch
         self.device = device
 
+    def clone(self):
+        """A second context with the same configuration on the same device (its own pyramid, lists and graphs).  Contexts
+        are not re-entrant but independent ones run concurrently: stream.FrameStream(pipeline=2) alternates consecutive
+        steps between an engine and its clone."""
+        e = Engine.__new__(Engine)
+        e.L = self.L
+        e.cfg = type(self.cfg).from_buffer_copy(self.cfg)
+        h = C.c_void_p()
+        _capi.check(self.L.siftmi_create(C.byref(e.cfg), self.device, C.byref(h)))
+        e.h = h
+        e.width, e.height, e.device = self.width, self.height, self.device
+        e.n_octaves, e.nspo, e.max_batch = self.n_octaves, self.nspo, self.max_batch
+        return e
+
     def close(self):
         if getattr(self, "h", None):
             self.L.siftmi_destroy(self.h)

@@ -7,7 +7,13 @@ whose handle is NULL and would otherwise select the context's own, unordered str
 With `overlap_gather` (the multi-GPU driver) the packed results alternate between TWO buffer sets and the all-gather of
 step k runs on a side stream: the kernels of step k+1 write the other set while RCCL reads this one over xGMI, so the
 exchange (7 peers x ~30 MB per rank and step on the fully connected mesh: a few ms, per-link bound) hides under compute
-instead of adding to every step.  A set is reused two steps later, after its gather has finished (event)."""
+instead of adding to every step.  A set is reused two steps later, after its gather has finished (event).
+
+With `pipeline=2` consecutive steps alternate between TWO contexts (the engine and a clone: two pyramids, two launch
+streams, two result sets).  A step is HBM-bound for its first three quarters (pyramid, extrema) and VALU-bound for the rest
+(orientation, descriptors); with two steps in flight the second's dense stages run under the first's keypoint stages
+(measured on MI355X, 64 x 1080p: 11.5 -> 10.5 ms per step; tools/overlap_experiment.py).  run() then no longer orders
+torch's current stream after the step: results_host(), all_gather() and wait() do, for the step they read."""
 import numpy as np
 import torch
 
@@ -21,22 +27,30 @@ class _ResultSet:
         self.counts = torch.zeros((2, frames, n_octaves), dtype=torch.int32, device=device)
         self.totals = torch.zeros(4, dtype=torch.int32, device=device)      # {n_kp, n_desc, overflow flags, 0}
         self.gather_done = None                                             # event: the side-stream gather that read this set
+        self.ready = None                                                   # event: the step that wrote this set (launch stream)
 
 
 class FrameStream:
-    def __init__(self, engine, frames_per_step, device, world_size=1, kp_per_frame=32768, desc_per_frame=49152, overlap_gather=False):
+    def __init__(self, engine, frames_per_step, device, world_size=1, kp_per_frame=32768, desc_per_frame=49152, overlap_gather=False,
+                 pipeline=1):
+        assert pipeline in (1, 2)
         self.eng = engine
+        self.engines = [engine] + [engine.clone() for _ in range(pipeline - 1)]
+        self.pipeline = pipeline
         self.F = frames_per_step
         self.device = device
         self.world = world_size
         self.kp_cap = kp_per_frame * frames_per_step
         self.desc_cap = desc_per_frame * frames_per_step
         self.overlap = bool(overlap_gather)
-        self.sets = [_ResultSet(self.kp_cap, self.desc_cap, frames_per_step, engine.n_octaves, device) for _ in range(2 if self.overlap else 1)]
+        self.sets = [_ResultSet(self.kp_cap, self.desc_cap, frames_per_step, engine.n_octaves, device)
+                     for _ in range(2 if (self.overlap or pipeline == 2) else 1)]
         self.cur = 0                                         # the set the last run() wrote
+        self.step_no = -1
         self.gathered = None
         self.exchange = smdist.ResultExchange(self.kp_cap, self.desc_cap)
-        self.launch_stream = torch.cuda.Stream(device=device)
+        self.launch_streams = [torch.cuda.Stream(device=device) for _ in self.engines]
+        self.launch_stream = self.launch_streams[0]          # the stream of the last run()
         self.gather_stream = torch.cuda.Stream(device=device) if self.overlap else None
         self.gather_events = []                              # (start, end) timing events of every all_gather() call
 
@@ -67,18 +81,30 @@ class FrameStream:
         else:
             fmt = _capi.FMT_GRAYF32
         es = d_frames.element_size()
-        if self.overlap:
-            self.cur ^= 1
+        self.step_no += 1
+        self.cur = self.step_no % len(self.sets)
+        eng = self.engines[self.step_no % len(self.engines)]          # pipeline = 2: contexts and result sets alternate together
+        self.launch_stream = self.launch_streams[self.step_no % len(self.engines)]
         rs = self.sets[self.cur]
         cur = torch.cuda.current_stream(self.device)
         self.launch_stream.wait_stream(cur)
         if rs.gather_done is not None:                       # the gather that read this set two steps ago
             self.launch_stream.wait_event(rs.gather_done)
         d_frames.record_stream(self.launch_stream)
-        self.eng.detect_describe_batch_device(self.F, d_frames.data_ptr(), fmt, d_frames.stride(1) * es, d_frames.stride(0) * es,
-                                              rs.kp.data_ptr(), self.kp_cap, rs.desc.data_ptr(), self.desc_cap,
-                                              rs.counts.data_ptr(), rs.totals.data_ptr(), self.launch_stream.cuda_stream)
-        cur.wait_stream(self.launch_stream)
+        eng.detect_describe_batch_device(self.F, d_frames.data_ptr(), fmt, d_frames.stride(1) * es, d_frames.stride(0) * es,
+                                         rs.kp.data_ptr(), self.kp_cap, rs.desc.data_ptr(), self.desc_cap,
+                                         rs.counts.data_ptr(), rs.totals.data_ptr(), self.launch_stream.cuda_stream)
+        rs.ready = torch.cuda.Event()
+        rs.ready.record(self.launch_stream)
+        if self.pipeline == 1:
+            cur.wait_stream(self.launch_stream)
+        # pipeline = 2: the next step must be able to start before this one ends, so nothing joins here; readers call wait()
+
+    def wait(self, previous=False):
+        """Order torch's current stream after the last step -- or the one before it -- (no host synchronisation)."""
+        rs = self.sets[(self.step_no - 1) % len(self.sets) if previous else self.cur]
+        if rs.ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(rs.ready)
 
     def all_gather(self, synchronous=False):
         """RCCL all-gather of the last step's packed results.  Default: payload sizes come from the previous step's counts, so
@@ -88,7 +114,7 @@ class FrameStream:
         rs = self.sets[self.cur]
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if self.overlap and not synchronous:
-            self.gather_stream.wait_stream(self.launch_stream)
+            self.gather_stream.wait_event(rs.ready)
             with torch.cuda.stream(self.gather_stream):
                 t0.record()
                 self.gathered = self.exchange.gather(rs.kp, rs.desc, rs.counts, rs.totals)
@@ -96,6 +122,7 @@ class FrameStream:
                 rs.gather_done = torch.cuda.Event()
                 rs.gather_done.record(self.gather_stream)
         else:
+            self.wait()
             t0.record()
             if synchronous:
                 self.gathered = smdist.gather_results(rs.kp, rs.desc, rs.counts, rs.totals)
@@ -111,8 +138,12 @@ class FrameStream:
         if self.overlap:
             torch.cuda.current_stream(self.device).wait_stream(self.gather_stream)
 
-    def results_host(self, allow_capacity=False):
-        rs = self.sets[self.cur]
+    def results_host(self, allow_capacity=False, previous=False):
+        """Packed results of the last step on the host; previous=True (two result sets only): of the step before it, which a
+        pipelined consumer reads while the last one is still running."""
+        assert not previous or (len(self.sets) == 2 and self.step_no >= 1)
+        rs = self.sets[(self.step_no - 1) % len(self.sets) if previous else self.cur]
+        self.wait(previous)
         tot = rs.totals.cpu().numpy()
         nk, nd = int(tot[0]), int(tot[1])
         if tot[2] and not allow_capacity:       # the condition the host-facing API reports as SIFTMI_E_CAPACITY

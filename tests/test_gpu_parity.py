@@ -700,7 +700,38 @@ def test_device_path_reports_overflow_and_orders_following_calls(sm):
     eng.close()
 
 
-def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm):
+def test_frame_stream_two_steps_in_flight_equal_one_at_a_time(sm):
+    """FrameStream(pipeline=2): consecutive steps alternate between two contexts on two streams and nothing joins them with
+    torch's current stream, so step k+1 is launched before step k's results are read.  Every step's packed results must be
+    byte-identical to the host API's for that step's frames (three frame sets: each context sees its inputs change)."""
+    import torch
+    from siftmetal_amd import stream as smstream
+    dev = torch.device("cuda", 0)
+    sets = [np.stack([blob_frame(640, 480, 20 * j + i, n_blobs=150 + 100 * j) for i in range(4)]) for j in range(3)]
+    eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
+    want = [eng.detect_describe_batch(f) for f in sets]
+    fs = smstream.FrameStream(eng, 4, device=dev, pipeline=2)
+    assert len(fs.engines) == 2 and fs.engines[1].h.value != eng.h.value
+    dsets = [torch.from_numpy(f).to(dev) for f in sets]
+
+    def check(r, j, step):
+        k, kc, d, dc = want[j]
+        assert (r["n_keypoints"], r["n_descriptors"], r["overflow_flags"]) == (len(k), len(d), 0), step
+        assert r["keypoints"].tobytes() == k.tobytes() and r["descriptors"].tobytes() == d.tobytes(), step
+        assert np.array_equal(r["counts"][0], kc) and np.array_equal(r["counts"][1], dc), step
+
+    n = 9
+    for step in range(n):
+        fs.run(dsets[step % 3])
+        if step >= 1:
+            check(fs.results_host(previous=True), (step - 1) % 3, step - 1)     # read step k-1 while step k runs
+    check(fs.results_host(), (n - 1) % 3, n - 1)
+    for e in fs.engines:
+        e.close()
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm, pipeline):
     """The multi-GPU driver's exchange path on one rank through RCCL: double-buffered result sets, the all-gather of step k on
     a side stream under the kernels of step k+1, payload sizes taken from the previous step.  Every step's gathered row must
     be exactly that step's own packed results (alternating frame sets make consecutive steps differ)."""
@@ -716,7 +747,7 @@ def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm):
         fb = np.stack([blob_frame(640, 480, 10 + i, n_blobs=300) for i in range(4)])
         eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
         want = [eng.detect_describe_batch(f) for f in (fa, fb)]
-        fs = smstream.FrameStream(eng, 4, device=dev, overlap_gather=True)
+        fs = smstream.FrameStream(eng, 4, device=dev, overlap_gather=True, pipeline=pipeline)
         fs.exchange.headroom = 8.0            # the two frame sets differ 3x in keypoints on purpose: size for the larger from the smaller
         da, db = torch.from_numpy(fa).to(dev), torch.from_numpy(fb).to(dev)
         gathered = []
@@ -733,7 +764,8 @@ def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm):
             assert g["keypoints"][0, :len(k) * smdist.KP_BYTES].cpu().numpy().tobytes() == k.tobytes(), step
             assert g["descriptors"][0, :len(d) * smdist.DESC_BYTES].cpu().numpy().tobytes() == d.tobytes(), step
             assert np.array_equal(g["counts"][0, 0].cpu().numpy(), kc) and np.array_equal(g["counts"][0, 1].cpu().numpy(), dc)
-        eng.close()
+        for e in fs.engines:
+            e.close()
     finally:
         dist.destroy_process_group()
 
