@@ -783,7 +783,15 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
+#ifdef SIFTMI_EXPERIMENT                                   // tools/phase_experiment.py: one phase of the step per call
+        const char *ph = getenv("SIFTMI_EXP_PHASE");
+        const int phase = ph ? atoi(ph) : 0;
+        if (phase != 2)
+#endif
         if ((rc = run_dense_detect(c, st, nf, px, format, row_stride, frame_stride, fork, f0 == 0))) return rc;
+#ifdef SIFTMI_EXPERIMENT
+        if (phase == 1) continue;
+#endif
         if (!fork) {                                       // forked: the per-octave chains ran them (run_dense_detect)
             if ((rc = run_refine(c, st, nf, -1))) return rc;
             if ((rc = run_describe(c, st, nf, -1))) return rc;

@@ -53,3 +53,15 @@ def step_alt():
     i = k[0] & 1; k[0] += 1
     with torch.cuda.stream(ss[i]): rs[i].run(d)
 print("alternating 64-frame steps over 2 contexts / 2 streams: %.3f ms per step" % timeit(step_alt, n=16, warm=6))
+for x in es: x.close()
+for depth in (3, 4):
+    es = [sm.Engine(W, H, n_octaves=4, nspo=3, max_batch=64) for _ in range(depth)]
+    rs = [smstream.FrameStream(x, F, device=dev) for x in es]
+    ss = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    k = [0]
+    def step_alt():
+        i = k[0] % depth; k[0] += 1
+        with torch.cuda.stream(ss[i]): rs[i].run(d)
+    print("alternating 64-frame steps over %d contexts / streams: %.3f ms per step" % (depth, timeit(step_alt, n=24, warm=12)))
+    del rs
+    for x in es: x.close()
