@@ -61,10 +61,11 @@ struct Decimate {
 // touching the input layer again.  With hb = the horizontally blurred input at the pixel,
 //     DoG = (G[s+1] - hb) + (hb - G[s]) = Ev + Eh,
 // Eh is known in the horizontal pass (the raw centre values are still in its registers) and Ev in the vertical pass (hb
-// is the centre tap's operand).  The horizontal pass leaves max|Eh| per (window row, cell) in LDS and the vertical pass
-// flags a cell when |Ev| + max|Eh| > 0.9999 thr for one of its pixels: a conservative bound (|DoG| <= |Ev| + |Eh|), so no
-// candidate row is ever skipped, and tight in practice (benchmark frames: 15.2 % of octave 0's cells flagged against
-// 12.2 % with the exact test).
+// is the centre tap's operand).  The horizontal pass leaves max|Eh| per (window row, 8-column sub-cell) in LDS -- a lane's
+// own 8 outputs, no cross-lane reduction -- and the vertical pass flags a cell when |Ev| + max|Eh| > 0.9999 thr for one of
+// its pixels: a conservative bound (|DoG| <= |Ev| + |Eh|), so no candidate row is ever skipped, and tight in practice
+// (benchmark frames, with the maximum still taken over the whole 64-column cell: 15.2 % of octave 0's cells flagged
+// against 12.2 % with the exact test; the sub-cells took 3 % off the extrema scan and 2-4 % off the flagged layers).
 struct Activity {
     unsigned char *dst;             // plane [h][ncell] of this DoG scale, frame 0 (nullptr = off)
     size_t frame_stride;            // bytes between frames
@@ -436,11 +437,11 @@ struct RingGeom {
     static_assert(S * 8 == NTHR && (REM == 0 || REM == 2) && (NPF4 * 4 + REM) * 8 == LW, "prefetch decomposition");
     static_assert(R <= 15 && S + 2 * R <= NR, "window must fit the ring");
     static_assert((NR & (NR - 1)) == 0, "ring size must be a power of two");
-    // max|Eh| per (ring row, cell) for the activity flags: in the first two halo columns of the row when no tap reads
-    // that float4 (R <= 4, 9 <= R <= 12), else behind the ring
-    static constexpr bool EHM_IN_ROW = RP - R >= 4;
+    // max|Eh| per (ring row, 8-column sub-cell) for the activity flags, behind the ring: 4 KB.  (At R <= 8 that makes
+    // exactly 40 KB per workgroup: four still fit a CU's 160 KB.)
+    static constexpr int NSUB = TW / 8;
     static constexpr size_t lds_bytes = (size_t)LW * NR * sizeof(float);
-    static constexpr size_t lds_bytes_act = lds_bytes + (EHM_IN_ROW ? 0 : (size_t)NR * 2 * sizeof(float));
+    static constexpr size_t lds_bytes_act = lds_bytes + (size_t)NR * NSUB * sizeof(float);
 };
 
 template <int R>
@@ -452,25 +453,6 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
     }
     __device__ __forceinline__ float operator()(int i) const { return w[i <= R ? i : 2 * R - i]; }
 };
-
-// max of a non-negative value over the 16 lanes of a DPP row, valid in the row's lane 15 (row_shr 1, 2, 4, 8: lane i ends
-// with the max over lanes i-15 ... i; lanes without a source keep their own value).  Pure VALU: __shfl_xor goes through
-// the LDS crossbar (ds_swizzle / ds_bpermute) and this runs once per horizontal-pass item.
-__device__ __forceinline__ float row16_max_to_lane15(float e) {
-    // bound_ctrl with old = 0: lanes without a source read 0, the identity of max over non-negative values, which lets the
-    // compiler fold the move into v_max_f32_dpp (one instruction per step instead of two)
-#define SIFTMI_DPP_MAX(ctrl) e = fmaxf(e, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), ctrl, 0xf, 0xf, true)))
-    SIFTMI_DPP_MAX(0x111); SIFTMI_DPP_MAX(0x112); SIFTMI_DPP_MAX(0x114); SIFTMI_DPP_MAX(0x118);
-#undef SIFTMI_DPP_MAX
-    return e;
-}
-
-__device__ __forceinline__ float row8_max_to_lane7(float e) {      // the same over groups of 8 lanes: valid in lanes 7 and 15 of a DPP row
-#define SIFTMI_DPP_MAX(ctrl) e = fmaxf(e, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), ctrl, 0xf, 0xf, true)))
-    SIFTMI_DPP_MAX(0x111); SIFTMI_DPP_MAX(0x112); SIFTMI_DPP_MAX(0x114);
-#undef SIFTMI_DPP_MAX
-    return e;
-}
 
 // Register prefetch and s_waitcnt: the S new rows of step st+1 are requested at the start of step st and written to LDS
 // at its end.  hipcc counts outstanding vector-memory operations per basic block and merges conservatively at joins, so
@@ -507,9 +489,9 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
     constexpr int TLW = LW / 2 + 4, TLH = S / 2 + 2, NPX = (TLW * TLH + G::NTHR - 1) / G::NTHR;   // luma tile of a step (input pixels)
     static_assert(!SEED || (TLW * TLH <= (S - 2 * R) * LW && !DEC && !ACT), "the luma tile borrows the dead rows of a ring half");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // max|Eh| of (ring row, cell): only with ACT (see RingGeom::EHM_IN_ROW)
+    // max|Eh| of (ring row, 8-column sub-cell): only with ACT
     auto x4 = [](int slot) { return H8 ? (slot & 1) << 2 : 0; };                 // XOR on a float offset inside ring row `slot` (see H8)
-    auto ehm = [&](int slot, int cell) -> float & { return G::EHM_IN_ROW ? lds[slot * LW + (cell ^ x4(slot))] : lds[LW * NR + slot * 2 + cell]; };
+    auto ehm = [&](int slot, int sub) -> float & { return lds[LW * NR + slot * G::NSUB + sub]; };
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware 1-D order (see blur2_kernel): frame, chunk, strip with the strip index fastest
@@ -705,13 +687,12 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                 static_assert((RP / 4) % 2 == 0, "the first output float4 of a lane must be an even one");
                 *reinterpret_cast<float4 *>(rowp + RP + D) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 *reinterpret_cast<float4 *>(rowp + RP + 4 - D) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                if (ACT) {                                  // max |hb - raw| over this row's 64-column cell (8 lanes x 8 columns)
+                if (ACT) {                                  // max |hb - raw| over this lane's 8 columns = one sub-cell
                     constexpr int C = RP - 4 * M0;
                     float e = fabsf(acc[0] - v[C + 0]);
 #pragma unroll
                     for (int k = 1; k < 8; k++) e = fmaxf(e, fabsf(acc[k] - v[C + k]));
-                    e = row8_max_to_lane7(e);
-                    if ((tid & 7) == 7) ehm(slot, (tid >> 3) & 1) = e;
+                    ehm(slot, item & 15) = e;
                 }
             }
         } else {
@@ -734,11 +715,11 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                 for (int k = 0; k < 4; k++) acc[k] = fmaf(tw(i), v[(RP - R - 4 * M0) + k + i], acc[k]);
             }
             *reinterpret_cast<float4 *>(rowp + RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            if (ACT) {                                      // max |hb - raw| over this row's 64-column cell (16 lanes x 4 columns)
+            if (ACT) {                                      // max |hb - raw| over an 8-column sub-cell = this lane's 4 columns and its neighbour's
                 constexpr int C = RP - 4 * M0;
-                const float e = row16_max_to_lane15(fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(acc[0] - v[C + 0]), fabsf(acc[1] - v[C + 1])), fabsf(acc[2] - v[C + 2])),
-                                                          fabsf(acc[3] - v[C + 3])));
-                if ((tid & 15) == 15) ehm(slot, (tid >> 4) & 1) = e;
+                float e = fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(acc[0] - v[C + 0]), fabsf(acc[1] - v[C + 1])), fabsf(acc[2] - v[C + 2])), fabsf(acc[3] - v[C + 3]));
+                e = fmaxf(e, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x111 /* row_shr:1 */, 0xf, 0xf, true)));
+                if (tid & 1) ehm(slot, (item & 31) >> 1) = e;
             }
         }
         }
@@ -775,7 +756,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             float eh_row[ACT ? RB : 1];                     // max|Eh| of this lane's cell under each output row: all RB LDS reads in one batch
             if (ACT) {
 #pragma unroll
-                for (int rr = 0; rr < RB; rr++) eh_row[rr] = ehm((st * S + wv * RB + rr - R + NR) & (NR - 1), lane >> 5);
+                for (int rr = 0; rr < RB; rr++) eh_row[rr] = ehm((st * S + wv * RB + rr - R + NR) & (NR - 1), lane >> 2);
             }
             stamp(3);
             const int gx = x0 + 2 * lane;

@@ -20,7 +20,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "$K" not in k: continue
-        acc[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[k[:70] + " grid=" + r.get("Grid_Size", "?")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
     for c, v in sorted(d.items()):
