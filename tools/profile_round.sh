@@ -7,8 +7,12 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/profile_$TAG
 rm -rf $OUT; mkdir -p $OUT
-# 1. per-kernel time of exactly the bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+# 1. per-kernel time of the bench command.  With two steps in flight (the default) kernels of the two contexts run
+#    concurrently and the trace's durations include the time they spend sharing the GPU; the per-kernel figures that
+#    bench.py's roofline object reports come from its one-step-at-a-time pass, so the trace they are compared with is
+#    taken with --pipeline 1 (every kernel alone on the GPU) and the trace of the default command is kept beside it.
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras --pipeline 1 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/bench_under_rocprof_pipelined.json 2> $OUT/bench_under_rocprof_pipelined.err
 # 2. HBM bytes of the blur kernel: the five octave-0 layer launches of the pipeline itself (8 frames per launch, one call),
 #    plus the calibration copy with the same access shapes and a known byte count (tools/ubench/pmc_calib.hip)
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -37,6 +41,12 @@ if trace:
         w.writerow(["kernel", "workgroups_x", "grid_y", "grid_z", "calls", "avg_us", "min_us", "max_us", "total_ms"])
         for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k[0], k[1], k[2], k[3], len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2), round(sum(v) / 1e6, 3)])
+pst = glob.glob(out + "/trace_pipelined/**/*kernel_stats.csv", recursive=True)
+if pst:
+    prow = list(csv.DictReader(open(pst[0])))
+    with open(out + "/rocprof_kernel_stats_%s_pipelined.csv" % tag, "w") as f:
+        if prow:
+            w = csv.DictWriter(f, fieldnames=list(prow[0].keys())); w.writeheader(); w.writerows(prow)
 for r in rows[:16]:
     print("%-74s calls %6s total_ns %12s avg_ns %10s pct %s" % (r.get("Name", "")[:74], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 
@@ -62,7 +72,7 @@ for key in sorted(fetch, key=lambda k: -k[1]):
     kname, grid = key
     f, wv = sorted(fetch[key]), sorted(write.get(key, [0.0]))
     fm, wm = f[len(f) // 2], wv[len(wv) // 2]
-    m = re.search(r"blur_ring_kernel<(\d+), \d+, \d+, (true|false), (true|false), \d+, (-?\d+)>", kname)
+    m = re.search(r"blur_ring_kernel<(\d+), \d+, \d+, (true|false), (true|false), \d+, (-?\d+)(?:, (?:true|false))?>", kname)
     hbm = (cal["FETCH_SIZE"] or 2.0) * fm * 1024 + (cal["WRITE_SIZE"] or 1.0) * wm * 1024
     res.append({"kernel": kname.replace("void siftmi::", ""), "grid": grid, "launches_sampled": len(f), "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm,
                 "hbm_bytes_per_launch_corrected": hbm, "radius": int(m.group(1)) if m else None, "seed": bool(m and int(m.group(4)) >= 0),
