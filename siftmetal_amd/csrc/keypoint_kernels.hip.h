@@ -33,7 +33,8 @@ namespace siftmi {
 #define SIFTMI_ORI_NCOPY 4                                 // same for the 36-bin histogram of orientation_kernel
 #endif
 constexpr int MAX_OCT = 16;
-constexpr int MAX_NG = 11;            // Gaussian layers per octave = nspo + 3, nspo <= 8
+constexpr int MAX_NG = 10;            // Gaussian layers per octave = nspo + 3, nspo <= 7 (at 8 the extrema walk needs 173 VGPRs and
+                                      // hipcc starts copying its in-flight load registers: tools/audit_asm_loads.py)
 constexpr int ORI_BINS = 36;
 constexpr int DESC_N = 128;
 
@@ -152,6 +153,9 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
         if constexpr (ND + 1 == 6) asm volatile("s_waitcnt vmcnt(12)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5])::"memory");
         if constexpr (ND + 1 == 7) asm volatile("s_waitcnt vmcnt(14)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6])::"memory");
         if constexpr (ND + 1 == 8) asm volatile("s_waitcnt vmcnt(16)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory");
+        if constexpr (ND + 1 == 9) asm volatile("s_waitcnt vmcnt(18)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]), "+v"(buf[8 % (ND + 1)])::"memory");
+        if constexpr (ND + 1 == 10) asm volatile("s_waitcnt vmcnt(20)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]), "+v"(buf[8 % (ND + 1)]), "+v"(buf[9 % (ND + 1)])::"memory");
+        static_assert(ND + 1 >= 4 && ND + 1 <= 10, "a wait statement per layer count (the registers it ties are the row's load destinations)");
 #pragma unroll
         for (int l = 0; l < ND; l++) {
             const float dv = buf[l + 1] - buf[l];

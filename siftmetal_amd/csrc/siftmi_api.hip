@@ -593,8 +593,7 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
         case 4: LAUNCH_EXT(4); break;
         case 5: LAUNCH_EXT(5); break;
         case 6: LAUNCH_EXT(6); break;
-        case 7: LAUNCH_EXT(7); break;
-        default: LAUNCH_EXT(8); break;
+        default: LAUNCH_EXT(7); break;
     }
 #undef LAUNCH_EXT
     HIP_TRY(hipGetLastError());

@@ -35,7 +35,7 @@ CASES = [
     ("tiny", (40, 36), 2, 3),
     ("nspo4", (256, 192), 3, 4),            # other scales-per-octave: different tap counts / layer counts
     ("nspo5", (200, 150), 2, 5),
-    ("nspo8", (232, 168), 2, 8),            # the most layers the kernels take (11 Gaussian / 10 DoG per octave), 5-tap first layer
+    ("nspo7", (232, 168), 2, 7),            # the most layers the kernels take (10 Gaussian / 9 DoG per octave), 7-tap first layer
     ("tall", (130, 700), 4, 3),             # marching kernel: several steps per strip, ragged last step
 ]
 
@@ -190,7 +190,7 @@ def test_errors_and_capacity(sm):
         sm.Engine(16, 16, n_octaves=7)                      # octave 6 would be empty
     assert e.value.code == _capi.E_BADARG
     with pytest.raises(sm.SiftmiError) as e:
-        sm.Engine(64, 64, nspo=9)
+        sm.Engine(64, 64, nspo=8)
     assert e.value.code == _capi.E_BADARG
     with pytest.raises(sm.SiftmiError) as e:
         sm.Engine(64, 64, device=99)
