@@ -462,7 +462,12 @@ static void t_collect(siftmi_ctx *c) {
 // pays 2R extra horizontally blurred rows for the chunk's prologue (20 % of a 128-row chunk at R = 13).  Tall octaves take
 // 256-row chunks (tools/ubench/blur_variants.hip, 32 x 3840x2160: 2-4 % faster than 128 at every radius; whole-height strips
 // are no faster and leave a worse tail); for 1920x1080 the shorter chunks win (more workgroups than resident slots).
-static int march_chunk_rows(int h) { return h >= 1600 ? 256 : 128; }
+static int march_chunk_rows(int h) {
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv(h >= 1600 ? "SIFTMI_EXP_CHUNK_BIG" : "SIFTMI_EXP_CHUNK_SMALL")) return atoi(e);
+#endif
+    return h >= 1600 ? 256 : 128;
+}
 
 // the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 2000)
 static bool uses_march(const siftmi_ctx *c, int w, int h, int nf) {
