@@ -33,7 +33,7 @@ class _ResultSet:
 class FrameStream:
     def __init__(self, engine, frames_per_step, device, world_size=1, kp_per_frame=32768, desc_per_frame=49152, overlap_gather=False,
                  pipeline=1):
-        assert pipeline in (1, 2)
+        assert 1 <= pipeline <= 4
         self.eng = engine
         self.engines = [engine] + [engine.clone() for _ in range(pipeline - 1)]
         self.pipeline = pipeline
@@ -44,7 +44,7 @@ class FrameStream:
         self.desc_cap = desc_per_frame * frames_per_step
         self.overlap = bool(overlap_gather)
         self.sets = [_ResultSet(self.kp_cap, self.desc_cap, frames_per_step, engine.n_octaves, device)
-                     for _ in range(2 if (self.overlap or pipeline == 2) else 1)]
+                     for _ in range(max(pipeline, 2 if self.overlap else 1))]
         self.cur = 0                                         # the set the last run() wrote
         self.step_no = -1
         self.gathered = None
@@ -83,7 +83,7 @@ class FrameStream:
         es = d_frames.element_size()
         self.step_no += 1
         self.cur = self.step_no % len(self.sets)
-        eng = self.engines[self.step_no % len(self.engines)]          # pipeline = 2: contexts and result sets alternate together
+        eng = self.engines[self.step_no % len(self.engines)]          # pipeline > 1: contexts and result sets rotate together
         self.launch_stream = self.launch_streams[self.step_no % len(self.engines)]
         rs = self.sets[self.cur]
         cur = torch.cuda.current_stream(self.device)
@@ -98,7 +98,7 @@ class FrameStream:
         rs.ready.record(self.launch_stream)
         if self.pipeline == 1:
             cur.wait_stream(self.launch_stream)
-        # pipeline = 2: the next step must be able to start before this one ends, so nothing joins here; readers call wait()
+        # pipeline > 1: the next step must be able to start before this one ends, so nothing joins here; readers call wait()
 
     def wait(self, previous=False):
         """Order torch's current stream after the last step -- or the one before it -- (no host synchronisation)."""
@@ -139,9 +139,9 @@ class FrameStream:
             torch.cuda.current_stream(self.device).wait_stream(self.gather_stream)
 
     def results_host(self, allow_capacity=False, previous=False):
-        """Packed results of the last step on the host; previous=True (two result sets only): of the step before it, which a
-        pipelined consumer reads while the last one is still running."""
-        assert not previous or (len(self.sets) == 2 and self.step_no >= 1)
+        """Packed results of the last step on the host; previous=True (two or more result sets): of the step before it, which
+        a pipelined consumer reads while the last one is still running."""
+        assert not previous or (len(self.sets) >= 2 and self.step_no >= 1)
         rs = self.sets[(self.step_no - 1) % len(self.sets) if previous else self.cur]
         self.wait(previous)
         tot = rs.totals.cpu().numpy()
