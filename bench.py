@@ -193,7 +193,8 @@ def main():
     eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
     # the timed stream: consecutive steps alternate between two contexts, so that step k+1's HBM-bound dense stages run under
     # step k's VALU-bound keypoint stages; `plain` (one context, one step at a time) is what the per-kernel measurements use
-    runner = smstream.FrameStream(eng, F, device=dev, world_size=world, overlap_gather=use_dist, pipeline=args.pipeline)
+    runner = smstream.FrameStream(eng, F, device=dev, world_size=world, overlap_gather=use_dist, pipeline=args.pipeline,
+                                  result_sets=args.pipeline + 1)
     plain = smstream.FrameStream(eng, F, device=dev) if args.pipeline > 1 else runner
 
     def barrier():
@@ -352,6 +353,30 @@ def main():
         del k, d
         eio.close()
         sm.pinned_release(pin)
+        # the same metric through the frame stream: uploads on a copy stream into alternating staging buffers, so the PCIe
+        # transfer of step k+1 runs under the kernels of step k, and step k's results are copied back while k+1 runs
+        hpin = torch.from_numpy(frames_np).pin_memory()
+        for _ in range(4):
+            runner.run_host(hpin)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        back = len(runner.sets) - 1                       # read step i - back after launching step i: the upload of step i+1 is
+        for i in range(args.steps):                       # then issued while steps i-1 and i still run
+            runner.run_host(hpin)
+            if i >= back:
+                rio = runner.results_host(back=back)
+        for b in range(back - 1, -1, -1):
+            rio = runner.results_host(back=b)
+        torch.cuda.synchronize()
+        ms_ios = (time.perf_counter() - t1) / args.steps * 1e3
+        if (rio["n_keypoints"], rio["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]):
+            raise SystemExit("bench: host-fed stream results differ from the resident ones")
+        out["config"]["host_io_stream"] = {"workload": "the same step through FrameStream.run_host: frames in page-locked host memory, upload of step k+1 under the kernels "
+                                                       "of step k (copy stream, alternating staging buffers), every step's packed keypoints + descriptors copied to the host",
+                                           "ms_per_step": round(ms_ios, 4), "Mpixels_per_s": round(F * W * H / ms_ios / 1e3, 1),
+                                           "h2d_bytes_per_step": int(hpin.numel()), "d2h_bytes_per_step": int(rio["keypoints"].nbytes + rio["descriptors"].nbytes)}
+        log("host i/o through the frame stream: %.3f ms/step (%.0f Mpixels/s)" % (ms_ios, F * W * H / ms_ios / 1e3))
+        del hpin
         # dense natural texture: the same step on 64 mirror-tiled butterfly frames (not sparse synthetic blobs)
         d_dense = torch.from_numpy(make_dense_frames(F)).to(dev)
         runner.run(d_dense)

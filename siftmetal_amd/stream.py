@@ -32,7 +32,7 @@ class _ResultSet:
 
 class FrameStream:
     def __init__(self, engine, frames_per_step, device, world_size=1, kp_per_frame=32768, desc_per_frame=49152, overlap_gather=False,
-                 pipeline=1):
+                 pipeline=1, result_sets=None):
         assert 1 <= pipeline <= 4
         self.eng = engine
         self.engines = [engine] + [engine.clone() for _ in range(pipeline - 1)]
@@ -44,7 +44,7 @@ class FrameStream:
         self.desc_cap = desc_per_frame * frames_per_step
         self.overlap = bool(overlap_gather)
         self.sets = [_ResultSet(self.kp_cap, self.desc_cap, frames_per_step, engine.n_octaves, device)
-                     for _ in range(max(pipeline, 2 if self.overlap else 1))]
+                     for _ in range(max(pipeline, 2 if self.overlap else 1, result_sets or 1))]
         self.cur = 0                                         # the set the last run() wrote
         self.step_no = -1
         self.gathered = None
@@ -53,6 +53,9 @@ class FrameStream:
         self.launch_stream = self.launch_streams[0]          # the stream of the last run()
         self.gather_stream = torch.cuda.Stream(device=device) if self.overlap else None
         self.gather_events = []                              # (start, end) timing events of every all_gather() call
+        self.copy_stream = None                              # run_host(): uploads, staging buffers and the step that last read each
+        self._staging, self._staging_read = [], []
+        self._uploaded = None
 
     # the buffers of the last step (what results_host / all_gather read)
     @property
@@ -90,6 +93,9 @@ class FrameStream:
         self.launch_stream.wait_stream(cur)
         if rs.gather_done is not None:                       # the gather that read this set two steps ago
             self.launch_stream.wait_event(rs.gather_done)
+        if self._uploaded is not None:                       # run_host(): the frames arrive on the copy stream
+            self.launch_stream.wait_event(self._uploaded)
+            self._uploaded = None
         d_frames.record_stream(self.launch_stream)
         eng.detect_describe_batch_device(self.F, d_frames.data_ptr(), fmt, d_frames.stride(1) * es, d_frames.stride(0) * es,
                                          rs.kp.data_ptr(), self.kp_cap, rs.desc.data_ptr(), self.desc_cap,
@@ -100,9 +106,35 @@ class FrameStream:
             cur.wait_stream(self.launch_stream)
         # pipeline > 1: the next step must be able to start before this one ends, so nothing joins here; readers call wait()
 
-    def wait(self, previous=False):
-        """Order torch's current stream after the last step -- or the one before it -- (no host synchronisation)."""
-        rs = self.sets[(self.step_no - 1) % len(self.sets) if previous else self.cur]
+    def run_host(self, h_frames):
+        """One step on frames in PAGE-LOCKED host memory (a pinned torch tensor, layouts as run()).  The upload goes to one of
+        pipeline + 1 staging buffers on a copy stream, ordered after the step that last read that buffer only: the PCIe
+        transfer of step k+1 runs under the kernels of step k.  Read results with results_host(previous=True) after
+        launching the next step to keep both engines busy."""
+        assert (not h_frames.is_cuda) and h_frames.is_pinned() and h_frames.shape[0] == self.F and h_frames.is_contiguous()
+        # (Letting the seed kernel read the page-locked frames over PCIe itself instead of staging them: 23.8 against 13.5-15.3 ms
+        # per 64 x 1080p step.)
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream(device=self.device)
+            n = self.pipeline + 1                            # one more than the steps in flight: an upload never waits for a running step
+            self._staging = [torch.empty(h_frames.shape, dtype=h_frames.dtype, device=self.device) for _ in range(n)]
+            self._staging_read = [None] * n
+        slot = (self.step_no + 1) % len(self._staging)
+        st = self._staging[slot]
+        assert st.shape == h_frames.shape and st.dtype == h_frames.dtype, "run_host: one frame layout per stream"
+        if self._staging_read[slot] is not None:
+            self.copy_stream.wait_event(self._staging_read[slot])
+        with torch.cuda.stream(self.copy_stream):
+            st.copy_(h_frames, non_blocking=True)
+            self._uploaded = torch.cuda.Event()
+            self._uploaded.record(self.copy_stream)
+        self.run(st)
+        self._staging_read[slot] = self.sets[self.cur].ready
+
+    def wait(self, previous=False, back=None):
+        """Order torch's current stream after the last step -- or the one `back` steps before it -- (no host synchronisation)."""
+        back = (1 if previous else 0) if back is None else back
+        rs = self.sets[(self.step_no - back) % len(self.sets)]
         if rs.ready is not None:
             torch.cuda.current_stream(self.device).wait_event(rs.ready)
 
@@ -138,12 +170,14 @@ class FrameStream:
         if self.overlap:
             torch.cuda.current_stream(self.device).wait_stream(self.gather_stream)
 
-    def results_host(self, allow_capacity=False, previous=False):
-        """Packed results of the last step on the host; previous=True (two or more result sets): of the step before it, which
-        a pipelined consumer reads while the last one is still running."""
-        assert not previous or (len(self.sets) >= 2 and self.step_no >= 1)
-        rs = self.sets[(self.step_no - 1) % len(self.sets) if previous else self.cur]
-        self.wait(previous)
+    def results_host(self, allow_capacity=False, previous=False, back=None):
+        """Packed results of the last step on the host; back=n (previous=True: n = 1): of the step n before it, which a
+        pipelined consumer reads while the later ones are still running (needs more than n result sets:
+        FrameStream(result_sets=...))."""
+        back = (1 if previous else 0) if back is None else back
+        assert 0 <= back < len(self.sets) and self.step_no >= back
+        rs = self.sets[(self.step_no - back) % len(self.sets)]
+        self.wait(back=back)
         tot = rs.totals.cpu().numpy()
         nk, nd = int(tot[0]), int(tot[1])
         if tot[2] and not allow_capacity:       # the condition the host-facing API reports as SIFTMI_E_CAPACITY

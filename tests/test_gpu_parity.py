@@ -731,6 +731,37 @@ def test_frame_stream_two_steps_in_flight_equal_one_at_a_time(sm):
 
 
 @pytest.mark.parametrize("pipeline", [1, 2])
+def test_frame_stream_host_fed_steps_equal_host_api(sm, pipeline):
+    """FrameStream.run_host: frames in page-locked host memory, uploaded on a copy stream into alternating staging buffers
+    (the upload of step k+1 may run while step k computes).  The host tensor is rewritten between steps as soon as the step
+    that uploaded it has been launched and its predecessor read -- every step must still see its own frames."""
+    import torch
+    from siftmetal_amd import stream as smstream
+    dev = torch.device("cuda", 0)
+    sets = [np.stack([blob_frame(640, 480, 30 * j + i, n_blobs=120 + 90 * j) for i in range(4)]) for j in range(3)]
+    eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
+    want = [eng.detect_describe_batch(f) for f in sets]
+    fs = smstream.FrameStream(eng, 4, device=dev, pipeline=pipeline)
+    pins = [torch.from_numpy(f).pin_memory() for f in sets]
+    n = 8
+    for step in range(n):
+        fs.run_host(pins[step % 3])
+        if step >= 1 and pipeline > 1:
+            r = fs.results_host(previous=True)
+            k, kc, d, dc = want[(step - 1) % 3]
+            assert r["keypoints"].tobytes() == k.tobytes() and r["descriptors"].tobytes() == d.tobytes(), step - 1
+        if pipeline == 1:
+            r = fs.results_host()
+            k, kc, d, dc = want[step % 3]
+            assert r["keypoints"].tobytes() == k.tobytes() and r["descriptors"].tobytes() == d.tobytes(), step
+    r = fs.results_host()
+    k, kc, d, dc = want[(n - 1) % 3]
+    assert r["keypoints"].tobytes() == k.tobytes() and r["descriptors"].tobytes() == d.tobytes()
+    for e in fs.engines:
+        e.close()
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
 def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm, pipeline):
     """The multi-GPU driver's exchange path on one rank through RCCL: double-buffered result sets, the all-gather of step k on
     a side stream under the kernels of step k+1, payload sizes taken from the previous step.  Every step's gathered row must
