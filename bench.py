@@ -194,7 +194,7 @@ def main():
     # the timed stream: consecutive steps alternate between two contexts, so that step k+1's HBM-bound dense stages run under
     # step k's VALU-bound keypoint stages; `plain` (one context, one step at a time) is what the per-kernel measurements use
     runner = smstream.FrameStream(eng, F, device=dev, world_size=world, overlap_gather=use_dist, pipeline=args.pipeline,
-                                  result_sets=args.pipeline + 1)
+                                  result_sets=2 * args.pipeline)
     plain = smstream.FrameStream(eng, F, device=dev) if args.pipeline > 1 else runner
 
     def barrier():
@@ -211,8 +211,8 @@ def main():
     step()
     barrier()
     first = runner.results_host()
-    if use_dist or args.pipeline > 1:   # both contexts' / result sets' launch sequences captured (second sighting each) before anything is timed
-        for _ in range(4):
+    if use_dist or args.pipeline > 1:   # every (context, result set) launch sequence captured (second sighting each) before anything is timed
+        for _ in range(2 * len(runner.sets)):
             step()
         barrier()
     dt = timed_steps(step, barrier, args.steps, args.warmup)
@@ -356,11 +356,11 @@ def main():
         # the same metric through the frame stream: uploads on a copy stream into alternating staging buffers, so the PCIe
         # transfer of step k+1 runs under the kernels of step k, and step k's results are copied back while k+1 runs
         hpin = torch.from_numpy(frames_np).pin_memory()
-        for _ in range(4):
+        for _ in range(2 * len(runner.sets) + 2):         # every (staging buffer, result set) pairing seen twice: captured, then replayed
             runner.run_host(hpin)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        back = len(runner.sets) - 1                       # read step i - back after launching step i: the upload of step i+1 is
+        back = args.pipeline                              # read step i - back after launching step i: the upload of step i+1 is
         for i in range(args.steps):                       # then issued while steps i-1 and i still run
             runner.run_host(hpin)
             if i >= back:

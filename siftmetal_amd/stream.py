@@ -43,8 +43,11 @@ class FrameStream:
         self.kp_cap = kp_per_frame * frames_per_step
         self.desc_cap = desc_per_frame * frames_per_step
         self.overlap = bool(overlap_gather)
-        self.sets = [_ResultSet(self.kp_cap, self.desc_cap, frames_per_step, engine.n_octaves, device)
-                     for _ in range(max(pipeline, 2 if self.overlap else 1, result_sets or 1))]
+        # a multiple of the number of contexts, so that a context always meets the same result sets: the library replays a
+        # captured launch sequence per (input, output, stream) signature, and every new pairing would be captured afresh
+        n_sets = max(pipeline, 2 if self.overlap else 1, result_sets or 1)
+        n_sets = (n_sets + pipeline - 1) // pipeline * pipeline
+        self.sets = [_ResultSet(self.kp_cap, self.desc_cap, frames_per_step, engine.n_octaves, device) for _ in range(n_sets)]
         self.cur = 0                                         # the set the last run() wrote
         self.step_no = -1
         self.gathered = None
@@ -108,7 +111,7 @@ class FrameStream:
 
     def run_host(self, h_frames):
         """One step on frames in PAGE-LOCKED host memory (a pinned torch tensor, layouts as run()).  The upload goes to one of
-        pipeline + 1 staging buffers on a copy stream, ordered after the step that last read that buffer only: the PCIe
+        a few (more than `pipeline`) staging buffers on a copy stream, ordered after the step that last read that buffer only: the PCIe
         transfer of step k+1 runs under the kernels of step k.  Read results with results_host(previous=True) after
         launching the next step to keep both engines busy."""
         assert (not h_frames.is_cuda) and h_frames.is_pinned() and h_frames.shape[0] == self.F and h_frames.is_contiguous()
@@ -116,7 +119,9 @@ class FrameStream:
         # per 64 x 1080p step.)
         if self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream(device=self.device)
-            n = self.pipeline + 1                            # one more than the steps in flight: an upload never waits for a running step
+            # more buffers than steps in flight, so that an upload never waits for a running step; as many as result sets when
+            # that is enough: buffer, result set and context then rotate together (one launch signature per buffer)
+            n = len(self.sets) if len(self.sets) > self.pipeline else 2 * self.pipeline
             self._staging = [torch.empty(h_frames.shape, dtype=h_frames.dtype, device=self.device) for _ in range(n)]
             self._staging_read = [None] * n
         slot = (self.step_no + 1) % len(self._staging)

@@ -778,7 +778,7 @@ def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm, pipeline):
         fb = np.stack([blob_frame(640, 480, 10 + i, n_blobs=300) for i in range(4)])
         eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
         want = [eng.detect_describe_batch(f) for f in (fa, fb)]
-        fs = smstream.FrameStream(eng, 4, device=dev, overlap_gather=True, pipeline=pipeline, result_sets=pipeline + 1)   # as bench.py builds it
+        fs = smstream.FrameStream(eng, 4, device=dev, overlap_gather=True, pipeline=pipeline, result_sets=2 * pipeline)   # as bench.py builds it
         fs.exchange.headroom = 8.0            # the two frame sets differ 3x in keypoints on purpose: size for the larger from the smaller
         da, db = torch.from_numpy(fa).to(dev), torch.from_numpy(fb).to(dev)
         gathered = []
