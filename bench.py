@@ -320,19 +320,35 @@ def main():
         e1 = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=1)
         r1 = smstream.FrameStream(e1, 1, device=dev)
         one = d_frames[:1].contiguous()
-        for _ in range(3):
+        for _ in range(5):
             r1.run(one)
+        torch.cuda.synchronize()
+        batches = []
+        n1 = 20
+        for _ in range(7):                                  # one call at a time is as much a host-side latency as a GPU one: median of 7 x 20 calls
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                r1.run(one)
+            torch.cuda.synchronize()
+            batches.append((time.perf_counter() - t1) / n1 * 1e3)
+        batches.sort()
+        ms1 = batches[len(batches) // 2]
+        out["config"]["single_frame"] = {"workload": "BASELINE configs[1]: one 1920x1080 frame per call, 4 octaves", "ms_per_frame": round(ms1, 4),
+                                         "ms_per_frame_best_of_7": round(batches[0], 4), "Mpixels_per_s": round(W * H / ms1 / 1e3, 1)}
+        r2 = smstream.FrameStream(e1, 1, device=dev, pipeline=2)     # two calls in flight (two contexts)
+        for _ in range(8):
+            r2.run(one)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        n1 = 30
-        for _ in range(n1):
-            r1.run(one)
+        for _ in range(100):
+            r2.run(one)
         torch.cuda.synchronize()
-        ms1 = (time.perf_counter() - t1) / n1 * 1e3
-        out["config"]["single_frame"] = {"workload": "BASELINE configs[1]: one 1920x1080 frame per call, 4 octaves", "ms_per_frame": round(ms1, 4),
-                                         "Mpixels_per_s": round(W * H / ms1 / 1e3, 1)}
-        log("single frame: %.3f ms (%.0f Mpixels/s)" % (ms1, W * H / ms1 / 1e3))
-        del r1, e1
+        ms2 = (time.perf_counter() - t1) / 100 * 1e3
+        out["config"]["single_frame"]["ms_per_frame_two_calls_in_flight"] = round(ms2, 4)
+        log("single frame: %.3f ms (%.0f Mpixels/s); two calls in flight: %.3f ms per frame" % (ms1, W * H / ms1 / 1e3, ms2))
+        for e in r2.engines[1:]:
+            e.close()
+        del r1, r2, e1
         # the metric as SURVEY.md 8d words it: frames cross PCIe from pinned host memory, packed results are copied back
         pin = sm.pinned_empty(frames_np.shape, np.uint8)
         pin[...] = frames_np
