@@ -466,6 +466,10 @@ __global__ __launch_bounds__(256) void refine_kernel(PyramidDesc P, DetectParams
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t *__restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
 }
+__global__ __launch_bounds__(256) void zero2_i32_kernel(int32_t *__restrict__ p, size_t n, int32_t *__restrict__ q, size_t m) {   // two ranges, one launch
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) q[i] = 0;
+}
 
 __global__ __launch_bounds__(1024) void kp_row_scan_kernel(PyramidDesc P, int32_t *__restrict__ row_count /* in: counts, out: zeros */,
                                                           int32_t *__restrict__ row_start) {
@@ -529,6 +533,65 @@ __global__ __launch_bounds__(256) void kp_row_rank_kernel(PyramidDesc P, const K
         const unsigned long long key = bucket_keys[base + j];
         const unsigned int row = (unsigned int)(key >> 32) / w;
         const int b0 = row_start[rbase + row], b1 = b0 + row_fill[rbase + row];
+        int rank = b0;
+        for (int k = b0; k < b1; k++) rank += (bucket_keys[base + k] < key) ? 1 : 0;
+        kp_sorted[base + rank] = kp_tmp[base + bucket_src[base + j]];
+    }
+}
+
+// The three steps in ONE launch for small launches (a frame or two, per-octave chains of a forked graph: every launch on a
+// chain costs its duration plus a dependency gap of several microseconds, and a single 1080p call is bound by exactly
+// that).  One 1024-thread workgroup per group; the bucket starts live in LDS (rows[] -- the caller checks that the
+// octave's (nspo + 2) h rows fit), the scatter advances them, so that afterwards bucket r is [rows[r-1], rows[r]).
+// Keys and source indices still go through global memory between the steps: __syncthreads() orders a workgroup's global
+// accesses, and none of those lines was read earlier in the kernel.
+__global__ __launch_bounds__(1024) void kp_row_sort_small_kernel(PyramidDesc P, const KeypointRec *__restrict__ kp_tmp,
+                                                                const unsigned long long *__restrict__ kp_keys, const int32_t *__restrict__ kp_count,
+                                                                int32_t *__restrict__ row_count /* in: counts, out: zeros */,
+                                                                unsigned long long *__restrict__ bucket_keys, int32_t *__restrict__ bucket_src,
+                                                                KeypointRec *__restrict__ kp_sorted) {
+    extern __shared__ int rows[];                          // [n_rows] bucket starts, then ends
+    __shared__ int wsum[16];
+    const int group = group_index(P, blockIdx.x), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n_rows = (P.nspo + 2) * P.h[o];
+    const int n = min(kp_count[group], P.cap_kp[o]);
+    const size_t rbase = (size_t)frame * P.row_frame + P.row_off[o], base = (size_t)frame * P.kp_frame + P.kp_off[o];
+    const unsigned int w = (unsigned int)P.w[o];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    {   // scan (as kp_row_scan_kernel)
+        const int per = (n_rows + 1023) / 1024;
+        const int r0 = min((int)threadIdx.x * per, n_rows), r1 = min(r0 + per, n_rows);
+        int sum = 0;
+        for (int r = r0; r < r1; r++) sum += row_count[rbase + r];
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int pos = incl - sum;
+        for (int k = 0; k < wv; k++) pos += wsum[k];
+        for (int r = r0; r < r1; r++) {
+            const int v = row_count[rbase + r];
+            rows[r] = pos;
+            row_count[rbase + r] = 0;
+            pos += v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {          // scatter (as kp_row_scatter_kernel)
+        const unsigned long long key = kp_keys[base + i];
+        const int slot = atomicAdd(&rows[(unsigned int)(key >> 32) / w], 1);
+        bucket_keys[base + slot] = key;
+        bucket_src[base + slot] = i;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 1024) {          // rank inside the bucket and move (as kp_row_rank_kernel)
+        const unsigned long long key = bucket_keys[base + j];
+        const unsigned int row = (unsigned int)(key >> 32) / w;
+        const int b0 = row ? rows[row - 1] : 0, b1 = rows[row];
         int rank = b0;
         for (int k = b0; k < b1; k++) rank += (bucket_keys[base + k] < key) ? 1 : 0;
         kp_sorted[base + rank] = kp_tmp[base + bucket_src[base + j]];
@@ -1002,7 +1065,8 @@ __global__ __launch_bounds__(256) void group_offsets_kernel(PyramidDesc P, int n
                                                            int32_t *__restrict__ kp_dst_off, int32_t *__restrict__ desc_dst_off,
                                                            int32_t *__restrict__ out_counts /* [2][total_frames][n_oct] */,
                                                            int32_t *__restrict__ stats /* [5][total_frames][n_oct] */,
-                                                           PackState *__restrict__ state, long long kp_capacity, long long desc_capacity) {
+                                                           PackState *__restrict__ state, long long kp_capacity, long long desc_capacity,
+                                                           int32_t *__restrict__ totals_out /* the caller's {n_kp, n_desc, flags, 0} after the last sub-batch, or null */) {
     // One 256-thread workgroup; the groups are scanned 256 at a time with the running totals carried in LDS.  The clamp of
     // a group against the OUTPUT capacity depends only on the unclamped total of the groups before it (T): destination
     // offset min(T, capacity), length clamp(capacity - T, 0, n) -- what a sequential walk with a clamped running total gives.
@@ -1056,6 +1120,7 @@ __global__ __launch_bounds__(256) void group_offsets_kernel(PyramidDesc P, int n
     }
     if (threadIdx.x == 0) {
         state->total_kp = (int)min(carry_k, kp_capacity); state->total_desc = (int)min(carry_d, desc_capacity); state->overflow_flags = s_flags;
+        if (totals_out) { totals_out[0] = state->total_kp; totals_out[1] = state->total_desc; totals_out[2] = s_flags; totals_out[3] = 0; }
     }
 }
 

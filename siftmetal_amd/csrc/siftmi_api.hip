@@ -626,9 +626,11 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     // Counters are cleared by a kernel, not hipMemsetAsync: memset nodes captured into the hipGraph stopped clearing from the
     // third launch of a serial graph on (ROCm 7.2; tests/test_gpu_parity.py::test_graph_replays_stay_correct).
     // the first sub-batch of a call also clears the running totals (PackState) that sit behind the counters
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters,
-                       5 * (size_t)c->B * c->n_oct + (first_of_call ? sizeof(PackState) / sizeof(int32_t) : 0));
-    if (fork) hipLaunchKernelGGL(zero_i32_kernel, dim3(64), dim3(256), 0, st, c->d_row_count, (size_t)nf * c->P.row_frame);   // for the per-octave refine launches
+    const size_t n_cnt = 5 * (size_t)c->B * c->n_oct + (first_of_call ? sizeof(PackState) / sizeof(int32_t) : 0);
+    if (fork)                                              // + the row buckets of the per-octave refine launches, in the same launch
+        hipLaunchKernelGGL(zero2_i32_kernel, dim3(64), dim3(256), 0, st, c->d_counters, n_cnt, c->d_row_count, (size_t)nf * c->P.row_frame);
+    else
+        hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters, n_cnt);
     t_begin(c, SIFTMI_T_SEED);
     HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed, nodec)));
     t_end(c);
@@ -689,6 +691,14 @@ static int run_refine(siftmi_ctx *c, hipStream_t st, int nf, int only_octave = -
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_SORT);
+    const size_t rows_bytes = only_octave >= 0 ? (size_t)(c->nspo + 2) * c->oh[only_octave] * sizeof(int32_t) : 0;
+    if (only_octave >= 0 && rows_bytes <= 60 * 1024) {     // a per-octave chain of a forked graph: one launch instead of three
+        hipLaunchKernelGGL(kp_row_sort_small_kernel, dim3(groups), dim3(1024), rows_bytes, st, P, c->d_kp_tmp, c->d_keys, cnt(c, C_KP), c->d_row_count,
+                           c->d_bucket_keys, c->d_bucket_src, c->d_kp);
+        HIP_TRY(hipGetLastError());
+        t_end(c);
+        return SIFTMI_OK;
+    }
     hipLaunchKernelGGL(kp_row_scan_kernel, dim3(groups), dim3(1024), 0, st, P, c->d_row_count, c->d_row_start);
     hipLaunchKernelGGL(kp_row_scatter_kernel, dim3(32, groups), dim3(256), 0, st, P, c->d_keys, cnt(c, C_KP), c->d_row_start, c->d_row_count,
                        c->d_bucket_keys, c->d_bucket_src);
@@ -727,13 +737,13 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
 }
 
 static int run_pack(siftmi_ctx *c, hipStream_t st, int nf, int frame_base, int total_frames, KeypointRec *kp_out, long long kp_cap,
-                    DescriptorRec *desc_out, long long desc_cap, int32_t *d_counts, int32_t *d_stats) {
+                    DescriptorRec *desc_out, long long desc_cap, int32_t *d_counts, int32_t *d_stats, int32_t *d_totals = nullptr) {
     const int groups = nf * c->n_oct;
     StageRange rg("siftmi pack results");
     t_begin(c, SIFTMI_T_PACK);
     hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(256), 0, st, c->P, nf, frame_base, total_frames, cnt(c, C_RAW), cnt(c, C_CAND),
                        cnt(c, C_KP), cnt(c, C_ORIENTED), cnt(c, C_DESC), c->d_dst_off, c->d_dst_off + (size_t)c->B * c->n_oct, d_counts,
-                       d_stats, c->d_state, kp_cap, desc_cap);
+                       d_stats, c->d_state, kp_cap, desc_cap, d_totals);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(pack_kernel, dim3(32, groups), dim3(256), 0, st, c->P, c->d_kp, c->d_desc, c->d_dst_off,
                        c->d_dst_off + (size_t)c->B * c->n_oct, d_counts, frame_base, total_frames, kp_out, desc_out);
@@ -800,10 +810,10 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
             if ((rc = run_refine(c, st, nf, -1))) return rc;
             if ((rc = run_describe(c, st, nf, -1))) return rc;
         }
-        if ((rc = run_pack(c, st, nf, f0, n_frames, d_kp, kp_cap, d_desc, desc_cap, d_counts, c->d_stats))) return rc;
+        // the last sub-batch's offsets kernel also writes the caller's {n_kp, n_desc, overflow flags, 0} (no copy node at the end)
+        if ((rc = run_pack(c, st, nf, f0, n_frames, d_kp, kp_cap, d_desc, desc_cap, d_counts, c->d_stats, f0 + nf >= n_frames ? d_totals : nullptr))) return rc;
         c->last_sub_frames = nf;
     }
-    if (d_totals) HIP_TRY(hipMemcpyAsync(d_totals, c->d_state, sizeof(PackState), hipMemcpyDeviceToDevice, st));   // {n_kp, n_desc, overflow flags, 0}
     return SIFTMI_OK;
 }
 
