@@ -420,6 +420,8 @@ def main():
     os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    runner.close()
+    eng.close()
     if use_dist:
         dist.barrier()                                      # rank 0's extra measurements are done: all ranks leave together
         dist.destroy_process_group()

@@ -60,6 +60,14 @@ class FrameStream:
         self._staging, self._staging_read = [], []
         self._uploaded = None
 
+    def close(self):
+        """Destroy the contexts this stream created (the clones of pipeline > 1); the engine it was given stays the caller's."""
+        torch.cuda.synchronize(self.device)
+        for e in self.engines[1:]:
+            e.close()
+        self.engines = self.engines[:1]
+        self.pipeline = 1
+
     # the buffers of the last step (what results_host / all_gather read)
     @property
     def kp(self):
