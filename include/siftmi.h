@@ -56,7 +56,7 @@ typedef enum siftmi_format {
 typedef struct siftmi_config {
     int32_t width, height;              /* inputSize                                              */
     int32_t n_octaves;                  /* numberOfOctaves = 7                                    */
-    int32_t nspo;                       /* numberOfScalesPerOctave = 3                            */
+    int32_t nspo;                       /* numberOfScalesPerOctave = 3 (accepted: 1 ... 7)        */
     float   sigma_min;                  /* sigmaMinimum = 0.8                                     */
     float   delta_min;                  /* deltaMinimum = 0.5 (only 0.5 is supported: 2x seed)    */
     float   sigma_in;                   /* sigmaInput = 0.5                                       */
