@@ -11,6 +11,11 @@ octave), frames already resident in HBM, results left in HBM; with N > 1 every r
 64 frames (frame-per-GPU sharding, weak scaling) and the step ends with the RCCL all-gather of the
 descriptor buffers.  Rank 0 prints ONE JSON line.
 
+The timed loop calls only the C ABI's frame stream (siftmi_stream_submit_device / siftmi_exchange_gather through the ctypes
+binding siftmetal_amd/stream.py): frames live in HBM allocated with siftmi_device_alloc, two steps in flight, host-fed
+staging and the RCCL exchange are all inside libsiftmi.so.  torch is used for the contract's synchronize() and, with
+N > 1, as the control plane only (gloo: hands rank 0's ncclUniqueId to the other ranks, barrier, max over ranks).
+
 `--gpus N` with N > 1 and no torchrun environment: this process spawns the N ranks itself (before any
 GPU call) and relays rank 0's line; it exits non-zero if fewer than N devices are visible or the
 process group does not come up with N ranks.
@@ -168,39 +173,50 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # SIFTMI_FORCE_GATHER=1 exercises the RCCL exchange with a single rank (smoke test on a 1-GPU box)
-    force_gather = os.environ.get("SIFTMI_FORCE_GATHER") == "1" and "RANK" in os.environ
+    force_gather = os.environ.get("SIFTMI_FORCE_GATHER") == "1"
     use_dist = world > 1 or force_gather
-    if use_dist:
+    if world > 1:
+        # control plane only (unique id, barrier, max over ranks): the data path's RCCL communicator lives in libsiftmi.so
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")
         if dist.get_world_size() != world:
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
 
     import __graft_entry__ as ge
     if local_rank == 0:                                     # one build per node; the others load the finished library
         ge.build()
-    if use_dist:
+    if world > 1:
         dist.barrier()
     import siftmetal_amd as sm
-    from siftmetal_amd import stream as smstream
+    from siftmetal_amd import _capi, stream as smstream
 
     F = args.frames
     frames_np = make_frames(F, args.distinct)
     # every rank gets different frames (rotate) so the gathered descriptors are not copies
     frames_np = np.roll(frames_np, rank, axis=0)
-    d_frames = torch.from_numpy(frames_np).to(dev)
+    d_frames = smstream.DeviceFrames(frames_np, local_rank)      # HBM through siftmi_device_alloc / siftmi_memcpy
     tune = {"blur_march_min_blocks": args.march_min_blocks} if args.march_min_blocks > 0 else {}
     eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
+    uid = None
+    if use_dist:
+        box = [smstream.Exchange.make_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        uid = box[0]
     # the timed stream: consecutive steps alternate between two contexts, so that step k+1's HBM-bound dense stages run under
     # step k's VALU-bound keypoint stages; `plain` (one context, one step at a time) is what the per-kernel measurements use
     runner = smstream.FrameStream(eng, F, device=dev, world_size=world, overlap_gather=use_dist, pipeline=args.pipeline,
-                                  result_sets=2 * args.pipeline)
+                                  result_sets=2 * args.pipeline, rank=rank, unique_id=uid)
     plain = smstream.FrameStream(eng, F, device=dev) if args.pipeline > 1 else runner
+
+    def dev_sync():
+        torch.cuda.synchronize()
+        _capi.check(_capi.load().siftmi_device_synchronize(local_rank))
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def step():
         runner.run(d_frames)
@@ -212,22 +228,29 @@ def main():
     barrier()
     first = runner.results_host()
     if use_dist or args.pipeline > 1:   # every (context, result set) launch sequence captured (second sighting each) before anything is timed
-        for _ in range(2 * len(runner.sets)):
+        for _ in range(2 * runner.n_sets):
             step()
         barrier()
+    g0 = runner.exchange.stats() if use_dist else None
     dt = timed_steps(step, barrier, args.steps, args.warmup)
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64)
+        gathered_dt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered_dt, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in gathered_dt]
+        dt = max(float(x.item()) for x in gathered_dt)
     ms_per_step = dt / args.steps * 1e3
     value = world * F * W * H * args.steps / dt / 1e6
-    gather_ms = None
+    gather_ms = gather_bytes = None
+    regathered = overflowed = 0
     if use_dist:
-        incomplete, overflowed = runner.exchange.finish()
-        if incomplete or overflowed:
-            raise SystemExit("bench: all-gather payloads were undersized in steps %s / list overflow in steps %s" % (incomplete, overflowed))
-        gather_ms = sum(a.elapsed_time(b) for a, b in runner.gather_events[-args.steps:]) / args.steps
+        regathered, overflowed = runner.exchange.finish()
+        if overflowed:
+            raise SystemExit("bench: list overflow in %d steps" % overflowed)
+        g1 = runner.exchange.stats()
+        gather_ms = (g1["ms"] - g0["ms"]) / max(g1["gathers"] - g0["gathers"], 1)
+        gather_bytes = g1["bytes_last"]
 
     res = runner.results_host()
     if (res["n_keypoints"], res["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]) or \
@@ -249,15 +272,21 @@ def main():
                       "pipelining": ("consecutive steps alternate between two contexts (two pyramids, two streams): a step's HBM-bound dense "
                                      "stages run under the previous step's VALU-bound keypoint stages; every step is computed in full, the "
                                      "timed region ends with a device synchronisation") if args.pipeline > 1 else None,
-                      "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                      "rccl_ranks": world if use_dist else 0,
+                      "ms_per_step_by_rank": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
                       "all_gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4),
-                      "all_gather": "side stream, double-buffered results: step k's exchange runs under step k+1's kernels" if use_dist else None,
+                      "all_gather_bytes_received_per_rank_per_step": gather_bytes,
+                      "all_gather_steps_regathered": regathered, "all_gather_steps_overflowed": overflowed,
+                      "all_gather": ("siftmi_exchange_gather (librccl inside libsiftmi.so) on a side stream, rotating result sets: step k's exchange "
+                                     "runs under step k+1's kernels; payload sizes from step k-1's totals") if use_dist else None,
+                      "host_binding": "ctypes -> siftmi_stream_* / siftmi_exchange_* (C ABI); no torch tensors or torch.distributed in the data path",
                       "keypoints_per_step_rank0": res["n_keypoints"], "descriptors_per_step_rank0": res["n_descriptors"]}}
 
     if rank == 0 and args.pipeline > 1:
         # the same K steps one at a time on one context: what the pipelining buys
-        dt1 = timed_steps(lambda: plain.run(d_frames), torch.cuda.synchronize, args.steps, 3)
+        dt1 = timed_steps(lambda: plain.run(d_frames), dev_sync, args.steps, 3)
         out["config"]["ms_per_step_one_in_flight"] = round(dt1 / args.steps * 1e3, 4)
+        out["ms_per_step_one_in_flight"] = out["config"]["ms_per_step_one_in_flight"]
         log("one step in flight: %.3f ms/step" % (dt1 / args.steps * 1e3))
     if rank == 0 and not args.no_roofline:
         # second, identical pass with per-launch hipEvents on the launch stream
@@ -265,7 +294,7 @@ def main():
         eng.reset_timings()
         for _ in range(args.steps):
             plain.run(d_frames)
-        torch.cuda.synchronize()
+        dev_sync()
         tm = eng.timings()
         eng.enable_timings(False)
         blur_ms, blur_n = tm["blur"]
@@ -319,17 +348,17 @@ def main():
         # BASELINE configs[1]: ONE 1920x1080 frame per call (lock-step batch 1, hipGraph replay), frame in HBM
         e1 = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=1)
         r1 = smstream.FrameStream(e1, 1, device=dev)
-        one = d_frames[:1].contiguous()
+        one = smstream.DeviceFrames(frames_np[:1], local_rank)
         for _ in range(5):
             r1.run(one)
-        torch.cuda.synchronize()
+        dev_sync()
         batches = []
         n1 = 20
         for _ in range(7):                                  # one call at a time is as much a host-side latency as a GPU one: median of 7 x 20 calls
             t1 = time.perf_counter()
             for _ in range(n1):
                 r1.run(one)
-            torch.cuda.synchronize()
+            dev_sync()
             batches.append((time.perf_counter() - t1) / n1 * 1e3)
         batches.sort()
         ms1 = batches[len(batches) // 2]
@@ -338,16 +367,15 @@ def main():
         r2 = smstream.FrameStream(e1, 1, device=dev, pipeline=2)     # two calls in flight (two contexts)
         for _ in range(8):
             r2.run(one)
-        torch.cuda.synchronize()
+        dev_sync()
         t1 = time.perf_counter()
         for _ in range(100):
             r2.run(one)
-        torch.cuda.synchronize()
+        dev_sync()
         ms2 = (time.perf_counter() - t1) / 100 * 1e3
         out["config"]["single_frame"]["ms_per_frame_two_calls_in_flight"] = round(ms2, 4)
         log("single frame: %.3f ms (%.0f Mpixels/s); two calls in flight: %.3f ms per frame" % (ms1, W * H / ms1 / 1e3, ms2))
-        for e in r2.engines[1:]:
-            e.close()
+        r1.close(); r2.close(); e1.close(); one.close()
         del r1, r2, e1
         # the metric as SURVEY.md 8d words it: frames cross PCIe from pinned host memory, packed results are copied back
         pin = sm.pinned_empty(frames_np.shape, np.uint8)
@@ -371,34 +399,39 @@ def main():
         sm.pinned_release(pin)
         # the same metric through the frame stream: uploads on a copy stream into alternating staging buffers, so the PCIe
         # transfer of step k+1 runs under the kernels of step k, and step k's results are copied back while k+1 runs
-        hpin = torch.from_numpy(frames_np).pin_memory()
-        for _ in range(2 * len(runner.sets) + 2):         # every (staging buffer, result set) pairing seen twice: captured, then replayed
+        hpin = sm.pinned_empty(frames_np.shape, np.uint8)
+        hpin[...] = frames_np
+        for _ in range(2 * runner.n_sets + 2):            # every (staging buffer, result set) pairing seen twice: captured, then replayed
             runner.run_host(hpin)
-        torch.cuda.synchronize()
+        dev_sync()
         t1 = time.perf_counter()
         back = args.pipeline                              # read step i - back after launching step i: the upload of step i+1 is
         for i in range(args.steps):                       # then issued while steps i-1 and i still run
             runner.run_host(hpin)
             if i >= back:
-                rio = runner.results_host(back=back)
+                rio = runner.results_host(back=back, copy=False)
         for b in range(back - 1, -1, -1):
-            rio = runner.results_host(back=b)
-        torch.cuda.synchronize()
+            rio = runner.results_host(back=b, copy=False)
+        dev_sync()
         ms_ios = (time.perf_counter() - t1) / args.steps * 1e3
         if (rio["n_keypoints"], rio["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]):
             raise SystemExit("bench: host-fed stream results differ from the resident ones")
-        out["config"]["host_io_stream"] = {"workload": "the same step through FrameStream.run_host: frames in page-locked host memory, upload of step k+1 under the kernels "
-                                                       "of step k (copy stream, alternating staging buffers), every step's packed keypoints + descriptors copied to the host",
+        out["config"]["host_io_stream"] = {"workload": "the same step through siftmi_stream_submit_host / siftmi_stream_result_host (C ABI): frames in page-locked host memory, "
+                                                       "upload of step k+1 under the kernels of step k (copy stream, rotating staging buffers), every step's packed "
+                                                       "keypoints + descriptors copied to page-locked host memory (copy started at submit time)",
                                            "ms_per_step": round(ms_ios, 4), "Mpixels_per_s": round(F * W * H / ms_ios / 1e3, 1),
-                                           "h2d_bytes_per_step": int(hpin.numel()), "d2h_bytes_per_step": int(rio["keypoints"].nbytes + rio["descriptors"].nbytes)}
+                                           "h2d_bytes_per_step": int(hpin.nbytes), "d2h_bytes_per_step": int(rio["keypoints"].nbytes + rio["descriptors"].nbytes)}
+        out["host_io_stream_ms_per_step"] = round(ms_ios, 4)          # SURVEY.md 8d's wording of the metric (PCIe in and out included)
+        out["host_io_stream_Mpixels_per_s"] = round(F * W * H / ms_ios / 1e3, 1)
         log("host i/o through the frame stream: %.3f ms/step (%.0f Mpixels/s)" % (ms_ios, F * W * H / ms_ios / 1e3))
-        del hpin
+        del rio
+        sm.pinned_release(hpin)
         # dense natural texture: the same step on 64 mirror-tiled butterfly frames (not sparse synthetic blobs)
-        d_dense = torch.from_numpy(make_dense_frames(F)).to(dev)
+        d_dense = smstream.DeviceFrames(make_dense_frames(F), local_rank)
         runner.run(d_dense)
-        torch.cuda.synchronize()
+        dev_sync()
         dres = runner.results_host()
-        dt_d = timed_steps(lambda: runner.run(d_dense), torch.cuda.synchronize, args.steps, 4)   # warm-up: both contexts capture this input's launch sequence
+        dt_d = timed_steps(lambda: runner.run(d_dense), dev_sync, args.steps, 4)   # warm-up: both contexts capture this input's launch sequence
         ms_d = dt_d / args.steps * 1e3
         out["config"]["dense"] = {"workload": "%d x 1920x1080 mirror-tiled butterfly frames (SURVEY.md 8d dense variant), resident in HBM" % F,
                                   "ms_per_step": round(ms_d, 4), "Mpixels_per_s": round(F * W * H / ms_d / 1e3, 1),
@@ -409,10 +442,11 @@ def main():
             eng.reset_timings()
             for _ in range(args.steps):
                 plain.run(d_dense)
-            torch.cuda.synchronize()
+            dev_sync()
             out["config"]["dense"]["stage_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in eng.timings().items()}
             eng.enable_timings(False)
-        del d_dense
+        dev_sync()
+        d_dense.close()
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(frames_np)
     sys.stdout.flush()
@@ -420,10 +454,13 @@ def main():
     os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()                                      # rank 0's extra measurements are done: all ranks leave together (the exchange is collective)
+    if plain is not runner:
+        plain.close()
     runner.close()
     eng.close()
-    if use_dist:
-        dist.barrier()                                      # rank 0's extra measurements are done: all ranks leave together
+    if world > 1:
         dist.destroy_process_group()
 
 

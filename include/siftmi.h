@@ -193,6 +193,157 @@ int siftmi_detect_describe_batch_device(siftmi_ctx *ctx, int32_t n_frames, const
 int siftmi_host_alloc(size_t bytes, void **ptr);
 int siftmi_host_free(void *ptr);
 
+/* Device memory for callers without a HIP toolchain of their own (a Swift / C host): frames that stay resident in HBM.
+   kind for siftmi_memcpy: 0 host -> device, 1 device -> host, 2 device -> device; synchronous. */
+int siftmi_device_alloc(int hip_device, size_t bytes, void **ptr);
+int siftmi_device_free(void *ptr);
+int siftmi_memcpy(void *dst, const void *src, size_t bytes, int kind);
+int siftmi_device_synchronize(int hip_device);
+
+/* ================================================================================================================
+   Frame stream: batches of frames ("steps") through detect + describe with several steps in flight.
+
+   Replaces the reference's single synchronous queue (SIFT/SIFT.swift:139-175: one MTLCommandQueue, commit +
+   waitUntilCompleted per stage) for a caller that feeds a stream of frames.  A stream borrows a context and creates
+   steps_in_flight - 1 more with the same configuration (contexts are not re-entrant, independent ones run
+   concurrently): consecutive steps alternate between them, each on its own launch stream, so the HBM-bound dense
+   stages of step k+1 run under the VALU-bound keypoint stages of step k.  Packed results go to `result_sets` rotating
+   device buffer sets (step k -> set k mod result_sets), so the results of step k stay valid until step
+   k + result_sets is submitted.  Nothing here blocks the host except the *_host result call and the explicit waits.
+
+   Stream arguments (`void *..._stream`) are hipStream_t handles: NULL is the device's legacy default stream,
+   SIFTMI_NO_STREAM means "no ordering wanted". */
+#define SIFTMI_NO_STREAM ((void *)(intptr_t)-1)
+
+typedef struct siftmi_stream siftmi_stream;
+
+typedef struct siftmi_stream_config {
+    int32_t frames_per_step;            /* F: frames per submit (a step); processed max_batch at a time              */
+    int32_t steps_in_flight;            /* 1 ... 4 contexts (default 2)                                               */
+    int32_t result_sets;                /* 0 = 2 x steps_in_flight; rounded up to a multiple of steps_in_flight       */
+    int32_t format;                     /* siftmi_format of every frame of the stream                                 */
+    int64_t kp_per_frame;               /* capacity of the packed outputs per frame (0 = 32768 / 49152)               */
+    int64_t desc_per_frame;
+    int32_t staging_buffers;            /* submit_host: device staging buffers (0 = as many as result sets)          */
+    int32_t reserved[7];
+} siftmi_stream_config;
+
+/* packed results of one step.  Device view: everything in HBM, nothing synchronised. */
+typedef struct siftmi_step_device {
+    int64_t step;                       /* step number (0, 1, ... in submit order)                                    */
+    const siftmi_keypoint *keypoints;   /* kp_capacity records, the first totals[0] valid, ordered (frame, octave)    */
+    const siftmi_descriptor *descriptors;
+    const int32_t *counts;              /* [2][frames_per_step][n_octaves]: keypoints, then descriptors               */
+    const int32_t *totals;              /* {n_keypoints, n_descriptors, overflow_flags, 0}                            */
+    int64_t kp_capacity, desc_capacity;
+} siftmi_step_device;
+
+/* Host view (page-locked memory owned by the stream, valid until the step's result set is reused). */
+typedef struct siftmi_step_host {
+    int64_t step;
+    const siftmi_keypoint *keypoints;
+    const siftmi_descriptor *descriptors;
+    const int32_t *counts;              /* [2][frames_per_step][n_octaves]                                            */
+    int32_t n_keypoints, n_descriptors;
+    int32_t overflow_flags;             /* != 0: a list was truncated (bits as siftmi_detect_describe_batch_device)   */
+    int32_t reserved;
+} siftmi_step_host;
+
+int  siftmi_stream_default_config(siftmi_stream_config *scfg, int32_t frames_per_step);
+/* ctx is borrowed (it stays the caller's and must outlive the stream); ctx->max_batch frames run in lock-step. */
+int  siftmi_stream_create(siftmi_ctx *ctx, const siftmi_stream_config *scfg, siftmi_stream **out);
+void siftmi_stream_destroy(siftmi_stream *s);
+/* the i-th context of the stream (0 = the borrowed one) for the introspection / timing calls */
+siftmi_ctx *siftmi_stream_context(siftmi_stream *s, int i);
+
+/* One step on frames resident in HBM.  The kernels are ordered after the work already enqueued on producer_stream
+   (the stream that wrote the frames; SIFTMI_NO_STREAM = frames are ready).  The frames must stay untouched until the
+   step has run (siftmi_stream_result_*, or siftmi_stream_wait_consumed). */
+int siftmi_stream_submit_device(siftmi_stream *s, const void *d_pixels, size_t row_stride, size_t frame_stride,
+                                void *producer_stream, int64_t *step);
+/* One step on frames in page-locked host memory (siftmi_host_alloc).  The upload goes to a rotating device staging
+   buffer on a copy stream and is ordered only after the step that last read that buffer: the PCIe transfer of step
+   k+1 runs under the kernels of step k.  `pixels` must stay untouched until siftmi_stream_wait_upload(step). */
+int siftmi_stream_submit_host(siftmi_stream *s, const void *pixels, size_t row_stride, size_t frame_stride, int64_t *step);
+/* host blocks until the frames of `step` have left host memory (submit_host) / have been read by the kernels (wait_consumed) */
+int siftmi_stream_wait_upload(siftmi_stream *s, int64_t step);
+int siftmi_stream_wait_consumed(siftmi_stream *s, int64_t step);
+
+/* Results of the step `back` steps before the last submitted one (0 = the last).  Device view: consumer_stream is
+   ordered after the step on the device (SIFTMI_NO_STREAM: no ordering); no host synchronisation. */
+int siftmi_stream_result_device(siftmi_stream *s, int back, siftmi_step_device *out, void *consumer_stream);
+/* Host view: blocks until the step has finished and its packed records are in page-locked host memory.  While the
+   caller keeps reading results on the host (a call of this function between two submits) the copy of a step is
+   started when the step is submitted (sized from the last counts read, completed here if the step found more), so a
+   pipelined consumer that reads step k after submitting step k+1 ... k+steps_in_flight finds it done.
+   Returns SIFTMI_E_CAPACITY (with valid truncated results in *out) if overflow_flags != 0. */
+int siftmi_stream_result_host(siftmi_stream *s, int back, siftmi_step_host *out);
+/* everything submitted so far has finished (host blocks) */
+int siftmi_stream_synchronize(siftmi_stream *s);
+
+/* ================================================================================================================
+   Result exchange between the GPUs of a node: RCCL all-gather of every rank's packed results (the one exchange step
+   of the path: frames are sharded frame-per-GPU, nothing else crosses GPUs).  One process per GPU; librccl is loaded
+   at the first siftmi_exchange_* call (no dependency for single-GPU users).
+
+   Per step: ncclAllGather of the totals, then padded all-gathers of counts, keypoint and descriptor bytes on a side
+   stream, reading the step's result set while the next step's kernels write another.  The payload sizes of step k
+   come from the totals of step k-1 (+ headroom), which are read on the host while step k runs: no host
+   synchronisation between a step's kernels and its collectives.  If a rank's counts outgrow what was sent (a scene
+   cut), the step is re-gathered in full by the NEXT siftmi_exchange_gather / siftmi_exchange_finish call, before its
+   result set can be reused; siftmi_exchange_result reports `complete`. */
+#define SIFTMI_UNIQUE_ID_BYTES 128
+typedef struct siftmi_exchange siftmi_exchange;
+
+typedef struct siftmi_gathered {
+    int64_t step;
+    int32_t world, complete;            /* complete = 0: some rank held more records than were sent (see above)      */
+    const uint8_t *keypoints;           /* device: [world][kp_stride] bytes; rank r's first totals[r][0] records valid */
+    const uint8_t *descriptors;         /* device: [world][desc_stride] bytes                                         */
+    const int32_t *counts;              /* device: [world][2][frames_per_step][n_octaves]                              */
+    const int32_t *totals_device;       /* device: [world][4]                                                         */
+    const int32_t *totals_host;         /* host:   [world][4], valid when `resolved` != 0                             */
+    int64_t kp_stride, desc_stride;     /* bytes between ranks = records sent per rank x record size                  */
+    int64_t kp_records, desc_records;   /* records sent per rank                                                       */
+    int32_t resolved, reserved;
+} siftmi_gathered;
+
+/* rank 0 creates the id and hands it to the other ranks out of band (a file, a socket, MPI, torch.distributed ...) */
+int  siftmi_exchange_unique_id(void *id /* SIFTMI_UNIQUE_ID_BYTES */);
+/* collective over the `world` ranks: ncclCommInitRank on the stream's device */
+int  siftmi_exchange_create(siftmi_stream *s, const void *unique_id, int rank, int world, siftmi_exchange **out);
+void siftmi_exchange_destroy(siftmi_exchange *x);
+/* collective: all-gather the results of the last submitted step (side stream, no host synchronisation unless
+   synchronous != 0, which sizes the payloads from this step's own totals) */
+int  siftmi_exchange_gather(siftmi_exchange *x, int synchronous);
+/* gathered results of the step `back` gathers ago (0 = the last, 1 = the one before: two buffer sets);
+   consumer_stream is ordered after the gather.  wait_host != 0: block until the gather has finished and the step's
+   totals are on the host (resolved = 1, complete is final). */
+int  siftmi_exchange_result(siftmi_exchange *x, int back, siftmi_gathered *out, void *consumer_stream, int wait_host);
+/* collective, end of stream: resolves (and if needed re-gathers) the last step; returns how many steps had to be
+   re-gathered and how many reported list overflow on some rank */
+int  siftmi_exchange_finish(siftmi_exchange *x, int64_t *regathered_steps, int64_t *overflow_steps);
+/* sizing rule of the following gathers: next size = (1 + headroom_percent / 100) x the largest count of the last resolved
+   step, rounded up to a multiple of quantum (defaults 25, 1024); the same on every rank */
+int  siftmi_exchange_set_headroom(siftmi_exchange *x, int32_t headroom_percent, int64_t quantum);
+/* accumulated GPU time of the gathers (side-stream hipEvents) and their number since creation; bytes received per gather */
+int  siftmi_exchange_stats(siftmi_exchange *x, double *ms, int64_t *gathers, int64_t *bytes_last);
+
+/* The sizing rule of the exchange alone (host arithmetic, no GPU, no RCCL): what siftmi_exchange_gather uses, exposed so
+   that the rule can be driven over any transport (tests/test_dist_gloo.py drives it over gloo on CPU). */
+typedef struct siftmi_gather_plan {
+    int64_t kp_capacity, desc_capacity; /* records per rank that the result buffers can hold                          */
+    int64_t send_kp, send_desc;         /* records per rank in the next payload gathers; -1 = not known yet           */
+    int64_t quantum;                    /* sizes are rounded up to a multiple of this (1024)                          */
+    int32_t headroom_percent;           /* 25: next size = 1.25 x the largest count seen in the last resolved step    */
+    int32_t reserved;
+    int64_t steps_resolved, steps_incomplete, steps_overflowed;
+} siftmi_gather_plan;
+int siftmi_gather_plan_init(siftmi_gather_plan *p, int64_t kp_capacity, int64_t desc_capacity);
+/* feed one step's totals of all ranks ([world][4] host ints) and what was sent for it; returns 1 if the step was
+   incomplete (some rank held more than was sent), 0 if not; updates send_kp / send_desc for the next step */
+int siftmi_gather_plan_resolve(siftmi_gather_plan *p, const int32_t *totals, int world, int64_t sent_kp, int64_t sent_desc);
+
 /* --- next row: SIFTDescriptor.match(source:target:absoluteThreshold:relativeThreshold:)
    (SIFT/SIFTDescriptor.swift:298-361), brute force + ratio test.  siftmi_match replaces
    SIFTCorrespondence (SIFT/SIFTCorrespondence.swift:11-16) with indices into the two input lists.

@@ -19,7 +19,16 @@ EXPORTS = [
     "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_dog", "siftmi_copy_extrema", "siftmi_copy_orientations",
     "siftmi_copy_descriptor_floats", "siftmi_enable_timings", "siftmi_reset_timings", "siftmi_get_timings",
     "siftmi_blur_algorithmic_bytes", "siftmi_get_blur_layer_timings", "siftmi_time_blur", "siftmi_synchronize",
+    "siftmi_device_alloc", "siftmi_device_free", "siftmi_memcpy", "siftmi_device_synchronize",
+    "siftmi_stream_default_config", "siftmi_stream_create", "siftmi_stream_destroy", "siftmi_stream_context",
+    "siftmi_stream_submit_device", "siftmi_stream_submit_host", "siftmi_stream_wait_upload", "siftmi_stream_wait_consumed",
+    "siftmi_stream_result_device", "siftmi_stream_result_host", "siftmi_stream_synchronize",
+    "siftmi_exchange_unique_id", "siftmi_exchange_create", "siftmi_exchange_destroy", "siftmi_exchange_gather",
+    "siftmi_exchange_result", "siftmi_exchange_finish", "siftmi_exchange_stats", "siftmi_exchange_set_headroom",
+    "siftmi_gather_plan_init", "siftmi_gather_plan_resolve",
 ]
+NO_STREAM = C.c_void_p(-1).value          # SIFTMI_NO_STREAM
+UNIQUE_ID_BYTES = 128
 
 
 class Config(C.Structure):
@@ -38,6 +47,34 @@ class Stats(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("n_octaves", C.c_int32)] + \
                [(n, C.POINTER(C.c_int32)) for n in ("raw_extrema", "candidates", "keypoints", "oriented", "descriptors")] + \
                [("raw_extrema_exact", C.c_int32)]
+
+
+class StreamConfig(C.Structure):         # siftmi_stream_config
+    _fields_ = [("frames_per_step", C.c_int32), ("steps_in_flight", C.c_int32), ("result_sets", C.c_int32), ("format", C.c_int32),
+                ("kp_per_frame", C.c_int64), ("desc_per_frame", C.c_int64), ("staging_buffers", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class StepDevice(C.Structure):           # siftmi_step_device
+    _fields_ = [("step", C.c_int64), ("keypoints", C.c_void_p), ("descriptors", C.c_void_p), ("counts", C.c_void_p), ("totals", C.c_void_p),
+                ("kp_capacity", C.c_int64), ("desc_capacity", C.c_int64)]
+
+
+class StepHost(C.Structure):             # siftmi_step_host
+    _fields_ = [("step", C.c_int64), ("keypoints", C.c_void_p), ("descriptors", C.c_void_p), ("counts", C.POINTER(C.c_int32)),
+                ("n_keypoints", C.c_int32), ("n_descriptors", C.c_int32), ("overflow_flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Gathered(C.Structure):             # siftmi_gathered
+    _fields_ = [("step", C.c_int64), ("world", C.c_int32), ("complete", C.c_int32), ("keypoints", C.c_void_p), ("descriptors", C.c_void_p),
+                ("counts", C.c_void_p), ("totals_device", C.c_void_p), ("totals_host", C.POINTER(C.c_int32)),
+                ("kp_stride", C.c_int64), ("desc_stride", C.c_int64), ("kp_records", C.c_int64), ("desc_records", C.c_int64),
+                ("resolved", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GatherPlan(C.Structure):           # siftmi_gather_plan
+    _fields_ = [("kp_capacity", C.c_int64), ("desc_capacity", C.c_int64), ("send_kp", C.c_int64), ("send_desc", C.c_int64),
+                ("quantum", C.c_int64), ("headroom_percent", C.c_int32), ("reserved", C.c_int32),
+                ("steps_resolved", C.c_int64), ("steps_incomplete", C.c_int64), ("steps_overflowed", C.c_int64)]
 
 
 extremum_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("scale", "<i4")])
@@ -107,6 +144,35 @@ def load():
     L.siftmi_blur_algorithmic_bytes.restype = C.c_int64
     L.siftmi_time_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.siftmi_synchronize.argtypes = [vp]
+    i64p = C.POINTER(C.c_int64)
+    L.siftmi_device_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp)]
+    L.siftmi_device_free.argtypes = [vp]
+    L.siftmi_memcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.siftmi_device_synchronize.argtypes = [C.c_int]
+    L.siftmi_stream_default_config.argtypes = [C.POINTER(StreamConfig), C.c_int32]
+    L.siftmi_stream_create.argtypes = [vp, C.POINTER(StreamConfig), C.POINTER(vp)]
+    L.siftmi_stream_destroy.argtypes = [vp]
+    L.siftmi_stream_destroy.restype = None
+    L.siftmi_stream_context.argtypes = [vp, C.c_int]
+    L.siftmi_stream_context.restype = vp
+    L.siftmi_stream_submit_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, i64p]
+    L.siftmi_stream_submit_host.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i64p]
+    L.siftmi_stream_wait_upload.argtypes = [vp, C.c_int64]
+    L.siftmi_stream_wait_consumed.argtypes = [vp, C.c_int64]
+    L.siftmi_stream_result_device.argtypes = [vp, C.c_int, C.POINTER(StepDevice), vp]
+    L.siftmi_stream_result_host.argtypes = [vp, C.c_int, C.POINTER(StepHost)]
+    L.siftmi_stream_synchronize.argtypes = [vp]
+    L.siftmi_exchange_unique_id.argtypes = [vp]
+    L.siftmi_exchange_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.siftmi_exchange_destroy.argtypes = [vp]
+    L.siftmi_exchange_destroy.restype = None
+    L.siftmi_exchange_gather.argtypes = [vp, C.c_int]
+    L.siftmi_exchange_result.argtypes = [vp, C.c_int, C.POINTER(Gathered), vp, C.c_int]
+    L.siftmi_exchange_finish.argtypes = [vp, i64p, i64p]
+    L.siftmi_exchange_set_headroom.argtypes = [vp, C.c_int32, C.c_int64]
+    L.siftmi_exchange_stats.argtypes = [vp, C.POINTER(C.c_double), i64p, i64p]
+    L.siftmi_gather_plan_init.argtypes = [C.POINTER(GatherPlan), C.c_int64, C.c_int64]
+    L.siftmi_gather_plan_resolve.argtypes = [C.POINTER(GatherPlan), vp, C.c_int, C.c_int64, C.c_int64]
     _lib = L
     return L
 

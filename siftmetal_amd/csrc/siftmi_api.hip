@@ -1519,3 +1519,8 @@ extern "C" int siftmi_synchronize(siftmi_ctx *c) {
     t_collect(c);
     return SIFTMI_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// frame stream (several steps in flight, host-fed staging, host result copies) and the RCCL result exchange
+#include "stream_api.hip.h"
+#include "exchange_api.hip.h"

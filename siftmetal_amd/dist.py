@@ -6,14 +6,20 @@ publishes its packed keypoint / descriptor buffers with ONE count exchange + pad
 (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 The functions here are device-agnostic tensor plumbing; no SIFT arithmetic.
 
-Two forms:
+The product exchange is siftmi_exchange_* inside libsiftmi.so (RCCL, siftmetal_amd/csrc/exchange_api.hip.h; bound by
+stream.Exchange).  This module holds what runs without a GPU: the sharding rule, a one-shot gather over
+torch.distributed, and ResultExchange -- the same per-step protocol as siftmi_exchange_gather over torch.distributed
+(gloo in the CPU tests), sized by the library's own rule (siftmi_gather_plan_*), so that the rule and the protocol
+(step-late sizing, re-gather of a step that was cut short) are covered on CPU with world size 2.
+
   gather_results   one-shot, sizes the payload gathers from the count exchange (one host sync).
   ResultExchange   for a frame stream: the payload gathers of step k are sized from the counts of
                    step k-1 (plus headroom), and the counts of step k are read on the host while step
                    k+1 runs -- no host synchronisation between a step's kernels and its collectives.
-                   A step whose counts turn out to exceed what was sent is reported one step late
-                   (`incomplete_steps`) and the caller re-gathers it with gather_results.
+                   A step whose counts turn out to exceed what was sent is gathered again in full by the
+                   next gather() / finish() call, while its result buffers are still intact.
 """
+import ctypes as C
 from typing import Dict, List, Optional
 
 import torch
@@ -71,50 +77,60 @@ def gather_results(kp_bytes: torch.Tensor, desc_bytes: torch.Tensor, counts: tor
 
 
 class ResultExchange:
-    """Per-step all-gather of a frame stream's packed results without a host synchronisation inside the step."""
+    """Per-step all-gather of a frame stream's packed results without a host synchronisation inside the step: the protocol of
+    siftmi_exchange_gather (include/siftmi.h) over torch.distributed, sized by siftmi_gather_plan_*."""
 
     def __init__(self, kp_capacity: int, desc_capacity: int, group=None, headroom: float = 1.25, quantum: int = 1024):
-        self.kp_capacity, self.desc_capacity = int(kp_capacity), int(desc_capacity)
-        self.group, self.headroom, self.quantum = group, float(headroom), int(quantum)
-        self.send_kp: Optional[int] = None               # records per rank in the payload gathers (None: not yet known)
-        self.send_desc: Optional[int] = None
-        self._pending = None                             # (step, host totals tensor, event or None, send_kp, send_desc)
+        from . import _capi
+        self._capi = _capi
+        self.L = _capi.load()
+        self.plan = _capi.GatherPlan()
+        _capi.check(self.L.siftmi_gather_plan_init(C.byref(self.plan), int(kp_capacity), int(desc_capacity)))
+        self.plan.headroom_percent = int(round((float(headroom) - 1.0) * 100))
+        self.plan.quantum = int(quantum)
+        self.group = group
+        self._pending = None                             # the previous step, not yet checked against what was sent for it
         self.step = 0
-        self.incomplete_steps: List[int] = []            # steps whose payload gathers were smaller than some rank's counts
+        self.regathered_steps: List[int] = []            # steps whose payload gathers were too small and were gathered again in full
         self.overflow_steps: List[int] = []              # steps in which some rank reported list overflow (d_totals[2])
 
-    def _round(self, n: int, cap: int) -> int:
-        n = int(n * self.headroom) + 1
-        n = (n + self.quantum - 1) // self.quantum * self.quantum
-        return max(1, min(n, cap))
-
     def _resolve_pending(self):
-        """Reads the counts of the previous step (its collectives finished long ago: the current step's kernels were
-        enqueued behind them before this is called) and re-sizes the payload gathers."""
+        """Reads the totals of the previous step (its collectives finished long ago: the current step's kernels were enqueued
+        behind them), re-gathers it in full if it was cut short, and re-sizes the payload gathers (siftmi_gather_plan_resolve)."""
         if self._pending is None:
             return
-        step, host, ev, sent_kp, sent_desc = self._pending
-        self._pending = None
-        if ev is not None:
-            ev.synchronize()
-        mk, md = int(host[:, 0].max()), int(host[:, 1].max())
-        if mk > sent_kp or md > sent_desc:
-            self.incomplete_steps.append(step)
+        p, self._pending = self._pending, None
+        if p["event"] is not None:
+            p["event"].synchronize()
+        host = p["host"]
+        t = host.numpy().astype("int32", copy=True)
+        inc = self.L.siftmi_gather_plan_resolve(C.byref(self.plan), t.ctypes.data, int(t.shape[0]), int(p["sent"][0]), int(p["sent"][1]))
+        self._capi.check(min(inc, 0))
         if int(host[:, 2].max()) != 0:
-            self.overflow_steps.append(step)
-        self.send_kp = self._round(max(mk, 1), self.kp_capacity)
-        self.send_desc = self._round(max(md, 1), self.desc_capacity)
+            self.overflow_steps.append(p["step"])
+        if inc == 1:                                     # every rank sees the same totals and takes the same decision: collective
+            mk = min(max(int(host[:, 0].max()), 1), int(self.plan.kp_capacity))
+            md = min(max(int(host[:, 1].max()), 1), int(self.plan.desc_capacity))
+            _, all_kp, all_desc = _payload_gathers(p["kp"], p["desc"], p["counts"], mk, md, self.group)
+            p["result"].update({"keypoints": all_kp, "descriptors": all_desc, "records_per_rank": (mk, md), "complete": True})
+            self.regathered_steps.append(p["step"])
+        else:
+            p["result"]["complete"] = True
 
     def gather(self, kp_bytes: torch.Tensor, desc_bytes: torch.Tensor, counts: torch.Tensor, totals: torch.Tensor) -> Dict[str, object]:
+        """The buffers of a step must stay intact until the next gather() / finish() has returned (a cut-short step is
+        gathered again from them) -- the frame stream's rotating result sets give exactly that."""
         world = dist.get_world_size(self.group)
         all_totals = torch.empty((world, TOTALS), dtype=torch.int32, device=totals.device)
         dist.all_gather_into_tensor(all_totals, _totals_row(totals), group=self.group)
         self._resolve_pending()
-        if self.send_kp is None:                         # first step: nothing to size from -> one synchronous read
+        first = self.plan.send_kp < 0
+        if first:                                        # first step: nothing to size from -> this step's own totals (one synchronous read)
             host = all_totals.cpu()
-            self.send_kp = self._round(max(int(host[:, 0].max()), 1), self.kp_capacity)
-            self.send_desc = self._round(max(int(host[:, 1].max()), 1), self.desc_capacity)
-        n_kp, n_desc = self.send_kp, self.send_desc
+            n_kp = min(max(int(host[:, 0].max()), 1), int(self.plan.kp_capacity))
+            n_desc = min(max(int(host[:, 1].max()), 1), int(self.plan.desc_capacity))
+        else:
+            n_kp, n_desc = int(self.plan.send_kp), int(self.plan.send_desc)
         all_counts, all_kp, all_desc = _payload_gathers(kp_bytes, desc_bytes, counts, n_kp, n_desc, self.group)
         if all_totals.is_cuda:
             host = torch.empty((world, TOTALS), dtype=torch.int32, pin_memory=True)
@@ -123,12 +139,14 @@ class ResultExchange:
             ev.record()
         else:
             host, ev = all_totals.clone(), None
-        self._pending = (self.step, host, ev, n_kp, n_desc)
+        result = {"totals_device": all_totals, "counts": all_counts, "keypoints": all_kp, "descriptors": all_desc,
+                  "records_per_rank": (n_kp, n_desc), "complete": False, "step": self.step}
+        self._pending = {"step": self.step, "host": host, "event": ev, "sent": (n_kp, n_desc), "kp": kp_bytes, "desc": desc_bytes,
+                         "counts": counts, "result": result}
         self.step += 1
-        return {"totals_device": all_totals, "counts": all_counts, "keypoints": all_kp, "descriptors": all_desc,
-                "records_per_rank": (n_kp, n_desc)}
+        return result
 
     def finish(self):
-        """Resolve the last step's counts (end of stream); returns (incomplete_steps, overflow_steps)."""
+        """Collective, end of stream: resolves (and if needed re-gathers) the last step; returns (regathered_steps, overflow_steps)."""
         self._resolve_pending()
-        return list(self.incomplete_steps), list(self.overflow_steps)
+        return list(self.regathered_steps), list(self.overflow_steps)

@@ -7,13 +7,15 @@ public final class SIFT {
         public init(inputSize: IntegralSize) { self.inputSize = inputSize }
     }
 
-    private var ctx: OpaquePointer?
-    private let octaveCount: Int
+    var ctx: OpaquePointer?                                    // internal: SIFTStream (SIFT+MI355X+Stream.swift) borrows it
+    let octaveCount: Int
 
-    /// `device`: HIP device ordinal (the Metal build takes an MTLDevice here).
-    public init(device: Int32 = 0, configuration: Configuration) {
+    /// `device`: HIP device ordinal (the Metal build takes an MTLDevice here); `batch`: frames processed in
+    /// lock-step per launch when the object feeds a `SIFTStream` (1 for getKeypoints / getDescriptors).
+    public init(device: Int32 = 0, configuration: Configuration, batch: Int = 1) {
         var cfg = siftmi_config()
         siftmi_default_config(&cfg, Int32(configuration.inputSize.width), Int32(configuration.inputSize.height))
+        cfg.max_batch = Int32(batch)
         octaveCount = Int(cfg.n_octaves)                       // 7, as DifferenceOfGaussians.swift:41
         let rc = siftmi_create(&cfg, device, &ctx)
         precondition(rc == SIFTMI_OK.rawValue, String(cString: siftmi_last_error()))

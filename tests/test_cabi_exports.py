@@ -39,6 +39,10 @@ def test_record_layouts_match_reference_structs():
     assert _capi.descriptor_reference_dtype.itemsize == 524
     assert _capi.descriptor_dtype.itemsize == 136
     assert C.sizeof(_capi.Config) == 4 * 29
+    # stream / exchange records: the sizes stream_api.hip.h static_asserts for the C structs
+    assert (C.sizeof(_capi.StreamConfig), C.sizeof(_capi.StepDevice), C.sizeof(_capi.StepHost), C.sizeof(_capi.Gathered),
+            C.sizeof(_capi.GatherPlan)) == (64, 56, 48, 96, 72)
+    assert _capi.NO_STREAM == 2 ** 64 - 1
 
 
 def test_defaults_are_the_reference_literals(lib):
@@ -90,15 +94,18 @@ def test_swift_stub_files_match_integration_md():
     blocks = re.findall(r"```(\w*)\n(.*?)```", txt, re.S)
     modmap = [b for lang, b in blocks if b.startswith("module CSiftmi")]
     swift = [b for lang, b in blocks if lang == "swift"]
-    assert len(modmap) == 1 and len(swift) == 2
+    assert len(modmap) == 1 and len(swift) == 3
     sw = os.path.join(ROOT, "swift", "Sources")
     assert open(os.path.join(sw, "CSiftmi", "module.modulemap")).read() == modmap[0]
     assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X.swift")).read() == swift[0]
     assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Match.swift")).read() == "import CSiftmi\n\n" + swift[1]
+    assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Stream.swift")).read() == swift[2]
     # every siftmi_* symbol the Swift uses is declared in the header
     hdr = open(os.path.join(ROOT, "include", "siftmi.h")).read()
-    used = set(re.findall(r"\b(siftmi_[a-z_0-9]+)\s*\(", swift[0] + swift[1]))
-    assert used and all(re.search(r"\b%s\s*\(" % u, hdr) for u in used - {"siftmi_config", "siftmi_keypoint", "siftmi_descriptor"}), used
+    used = set(re.findall(r"\b(siftmi_[a-z_0-9]+)\s*\(", swift[0] + swift[1] + swift[2]))
+    structs = {"siftmi_config", "siftmi_keypoint", "siftmi_descriptor", "siftmi_stream_config", "siftmi_step_host", "siftmi_gathered"}
+    assert used and all(re.search(r"\b%s\s*\(" % u, hdr) for u in used - structs), used
+    assert "siftmi_stream_submit_host" in used and "siftmi_exchange_gather" in used
     man = open(os.path.join(ROOT, "swift", "Package.swift")).read()
     assert '.systemLibrary(name: "CSiftmi"' in man and '.linkedLibrary("siftmi")' in man
 

@@ -104,8 +104,9 @@ def test_gather_results_world2_gloo():
 
 
 def _exchange_worker(rank, world, port, q):
-    """ResultExchange over three steps: payload gathers of step k sized from step k-1; a step whose counts outgrow the
-    previous step's size (plus headroom) is reported as incomplete one step late."""
+    """ResultExchange (the protocol of siftmi_exchange_gather over gloo, sized by the library's siftmi_gather_plan_*) over four
+    steps: payload gathers of step k sized from step k-1; a step whose counts outgrow that (a >25 % jump at the default headroom)
+    is gathered again in full by the next call, from buffers the caller has kept intact (the stream's rotating result sets)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -114,19 +115,26 @@ def _exchange_worker(rank, world, port, q):
         cap = 4096
         ex = smdist.ResultExchange(cap, cap, headroom=1.25, quantum=64)
         rng = np.random.default_rng(100 + rank)
-        got = []
-        for step, (nk, nd) in enumerate([(100 + 10 * rank, 120 + 7 * rank), (110 + 3 * rank, 90), (900 + rank, 1000)]):
-            kp = torch.from_numpy(rng.integers(0, 256, cap * smdist.KP_BYTES, dtype=np.uint8))
+        got, results = [], []
+        sizes = [(100 + 10 * rank, 120 + 7 * rank), (110 + 3 * rank, 90), (900 + rank, 1000), (50, 60 + rank)]
+        for step, (nk, nd) in enumerate(sizes):
+            kp = torch.from_numpy(rng.integers(0, 256, cap * smdist.KP_BYTES, dtype=np.uint8))      # a fresh buffer per step = a rotating result set
             ds = torch.from_numpy(rng.integers(0, 256, cap * smdist.DESC_BYTES, dtype=np.uint8))
             counts = torch.full((2, 3, 2), step + rank, dtype=torch.int32)
             totals = torch.tensor([nk, nd, 0, 0], dtype=torch.int32)
             g = ex.gather(kp, ds, counts, totals)
-            got.append({"sent": g["records_per_rank"], "totals": g["totals_device"].numpy().copy(),
-                        "own_kp": kp[:nk * smdist.KP_BYTES].numpy().tobytes(),
-                        "rows_kp": [g["keypoints"][r, :min(int(g["totals_device"][r, 0]), g["records_per_rank"][0]) * smdist.KP_BYTES].numpy().tobytes()
-                                    for r in range(world)]})
-        incomplete, overflow = ex.finish()
-        q.put({"rank": rank, "steps": got, "incomplete": incomplete, "overflow": overflow})
+            results.append(g)
+            got.append({"sent_first": g["records_per_rank"], "complete_at_once": bool(g["complete"]), "totals": g["totals_device"].numpy().copy(),
+                        "own_kp": kp[:nk * smdist.KP_BYTES].numpy().tobytes(), "own_desc": ds[:nd * smdist.DESC_BYTES].numpy().tobytes()})
+        regathered, overflow = ex.finish()
+        for step, g in enumerate(results):               # after finish() every step is complete, re-gathered ones included
+            tot = g["totals_device"].numpy()
+            got[step]["complete"] = bool(g["complete"])
+            got[step]["sent"] = g["records_per_rank"]
+            got[step]["rows_kp"] = [g["keypoints"][r, :int(tot[r, 0]) * smdist.KP_BYTES].numpy().tobytes() for r in range(world)]
+            got[step]["rows_desc"] = [g["descriptors"][r, :int(tot[r, 1]) * smdist.DESC_BYTES].numpy().tobytes() for r in range(world)]
+        q.put({"rank": rank, "steps": got, "regathered": regathered, "overflow": overflow,
+               "plan": (int(ex.plan.steps_resolved), int(ex.plan.steps_incomplete), int(ex.plan.send_kp), int(ex.plan.send_desc))})
     finally:
         dist.destroy_process_group()
 
@@ -145,12 +153,38 @@ def test_result_exchange_world2_gloo_sizes_from_previous_step():
         p.join(60)
         assert p.exitcode == 0
     for o in outs:
-        # step 0 sizes from its own counts (first step), step 1 from step 0, step 2 from step 1 -> too small for 900 / 1000 records
-        assert o["incomplete"] == [2] and o["overflow"] == []
-        assert o["steps"][0]["sent"][0] >= 110 and o["steps"][1]["sent"][0] >= 113
-        assert o["steps"][2]["sent"][0] < 900
+        # step 0 sizes from its own counts (first step), step 1 from step 0, step 2 from step 1 -> too small for 900 / 1000 records:
+        # gathered again in full by the call for step 3; step 3 is sized from step 2
+        assert o["regathered"] == [2] and o["overflow"] == []
+        assert o["plan"][0] == 4 and o["plan"][1] == 1
+        assert o["steps"][0]["sent_first"] == (110, 127)                 # exact: the maxima over the two ranks
+        assert o["steps"][1]["sent_first"] == (192, 192)                 # 1.25 x 110 + 1 -> 138 -> next multiple of 64; 1.25 x 127 + 1 = 159 -> 192
+        assert o["steps"][2]["sent_first"] == (192, 128) and o["steps"][2]["sent"] == (901, 1000)
+        assert o["steps"][3]["sent_first"] == (1152, 1280)
+        assert all(st["complete"] for st in o["steps"])
         assert np.array_equal(o["steps"][1]["totals"][:, 0], [110, 113])
-    for step in range(2):                      # complete steps: every rank holds every rank's exact keypoint bytes
+    for step in range(4):                      # every rank holds every rank's exact keypoint and descriptor bytes, the re-gathered step included
         for viewer in outs:
             for r in range(world):
-                assert viewer["steps"][step]["rows_kp"][r] == outs[r]["steps"][step]["own_kp"]
+                assert viewer["steps"][step]["rows_kp"][r] == outs[r]["steps"][step]["own_kp"], (step, r)
+                assert viewer["steps"][step]["rows_desc"][r] == outs[r]["steps"][step]["own_desc"], (step, r)
+
+
+def test_gather_plan_rule_matches_its_statement():
+    """siftmi_gather_plan_* (the sizing rule of siftmi_exchange_gather): next size = (1 + headroom) x the largest count of the
+    resolved step + 1, rounded up to the quantum, clamped to the capacity; a step is incomplete when any rank held more than
+    was sent; overflow flags are counted."""
+    import ctypes as C
+    from siftmetal_amd import _capi
+    L = _capi.load()
+    p = _capi.GatherPlan()
+    assert L.siftmi_gather_plan_init(C.byref(p), 5000, 300) == 0
+    assert (p.send_kp, p.send_desc, p.quantum, p.headroom_percent) == (-1, -1, 1024, 25)
+    t = np.array([[1000, 100, 0, 0], [2000, 250, 0, 0], [5, 5, 4, 0]], np.int32)
+    assert L.siftmi_gather_plan_resolve(C.byref(p), t.ctypes.data, 3, 2000, 250) == 0
+    assert (p.send_kp, p.send_desc) == (3072, 300)                       # 2501 -> 3072; 313 -> clamped to the capacity 300
+    assert (p.steps_resolved, p.steps_incomplete, p.steps_overflowed) == (1, 0, 1)
+    assert L.siftmi_gather_plan_resolve(C.byref(p), t.ctypes.data, 3, 1999, 250) == 1
+    assert L.siftmi_gather_plan_resolve(C.byref(p), t.ctypes.data, 3, 2000, 249) == 1
+    assert p.steps_incomplete == 2
+    assert L.siftmi_gather_plan_resolve(None, t.ctypes.data, 3, 0, 0) == _capi.E_BADARG

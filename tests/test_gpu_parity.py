@@ -763,42 +763,184 @@ def test_frame_stream_host_fed_steps_equal_host_api(sm, pipeline):
 
 @pytest.mark.parametrize("pipeline", [1, 2])
 def test_frame_stream_overlapped_all_gather_single_rank_rccl(sm, pipeline):
-    """The multi-GPU driver's exchange path on one rank through RCCL: double-buffered result sets, the all-gather of step k on
-    a side stream under the kernels of step k+1, payload sizes taken from the previous step.  Every step's gathered row must
-    be exactly that step's own packed results (alternating frame sets make consecutive steps differ)."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    from siftmetal_amd import dist as smdist, stream as smstream
-    dev = torch.device("cuda", 0)
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
-    try:
-        fa = np.stack([blob_frame(640, 480, i) for i in range(4)])
-        fb = np.stack([blob_frame(640, 480, 10 + i, n_blobs=300) for i in range(4)])
-        eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
-        want = [eng.detect_describe_batch(f) for f in (fa, fb)]
-        fs = smstream.FrameStream(eng, 4, device=dev, overlap_gather=True, pipeline=pipeline, result_sets=2 * pipeline)   # as bench.py builds it
-        fs.exchange.headroom = 8.0            # the two frame sets differ 3x in keypoints on purpose: size for the larger from the smaller
-        da, db = torch.from_numpy(fa).to(dev), torch.from_numpy(fb).to(dev)
-        gathered = []
-        for step in range(8):
-            fs.run(da if step % 2 == 0 else db)
-            gathered.append(fs.all_gather())
-        torch.cuda.synchronize()
-        incomplete, overflow = fs.exchange.finish()
-        assert incomplete == [] and overflow == []
-        for step, g in enumerate(gathered):
-            k, kc, d, dc = want[step % 2]
-            tot = g["totals_device"].cpu().numpy()
-            assert tot[0, 0] == len(k) and tot[0, 1] == len(d) and tot[0, 2] == 0
-            assert g["keypoints"][0, :len(k) * smdist.KP_BYTES].cpu().numpy().tobytes() == k.tobytes(), step
-            assert g["descriptors"][0, :len(d) * smdist.DESC_BYTES].cpu().numpy().tobytes() == d.tobytes(), step
-            assert np.array_equal(g["counts"][0, 0].cpu().numpy(), kc) and np.array_equal(g["counts"][0, 1].cpu().numpy(), dc)
-        for e in fs.engines:
-            e.close()
-    finally:
-        dist.destroy_process_group()
+    """The multi-GPU driver's exchange path on one rank through RCCL, all of it inside libsiftmi.so (siftmi_exchange_*):
+    rotating result sets, the all-gather of step k on a side stream under the kernels of step k+1, payload sizes taken from
+    the previous step.  The two frame sets differ 2x in keypoints, so at the default 25 % headroom every step from the small
+    to the large set is cut short and must be gathered again in full by the next call (it used to be returned
+    truncated).  Every step's gathered row, read one step late, must be exactly that step's own packed results."""
+    from siftmetal_amd import stream as smstream
+    fa = np.stack([blob_frame(640, 480, i) for i in range(4)])
+    fb = np.stack([blob_frame(640, 480, 10 + i, n_blobs=300) for i in range(4)])
+    eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
+    want = [eng.detect_describe_batch(f) for f in (fa, fb)]
+    nk = [len(w[0]) for w in want]
+    big = int(nk[1] > nk[0])                                   # which of the two frame sets holds more
+    assert nk[big] > 1.5 * nk[1 - big] > 300
+    fs = smstream.FrameStream(eng, 4, overlap_gather=True, pipeline=pipeline, result_sets=2 * pipeline)   # as bench.py builds it
+    fs.exchange.set_headroom(25, 16)
+    da, db = smstream.DeviceFrames(fa), smstream.DeviceFrames(fb)
+
+    def check(g, step):
+        k, kc, d, dc = want[step % 2]
+        assert g["step"] == step and g["complete"], (step, g["complete"])
+        assert g["totals"][0, 0] == len(k) and g["totals"][0, 1] == len(d) and g["totals"][0, 2] == 0
+        assert g["keypoints"][0].tobytes() == k.tobytes() and g["descriptors"][0].tobytes() == d.tobytes(), step
+        assert np.array_equal(g["counts"][0, 0], kc) and np.array_equal(g["counts"][0, 1], dc)
+
+    n = 8
+    first_look_incomplete = 0
+    for step in range(n):
+        fs.run(da if step % 2 == 0 else db)
+        fs.all_gather()
+        if step >= 1:
+            check(fs.exchange.result_host(back=1), step - 1)       # after gather(k), step k-1 is complete whatever its size was
+        g_now = fs.exchange.result(back=0, wait_host=True)
+        first_look_incomplete += 0 if g_now.complete else 1
+    regathered, overflowed = fs.exchange.finish()
+    check(fs.exchange.result_host(back=0), n - 1)
+    assert overflowed == 0
+    expect = sum(1 for k in range(1, n) if k % 2 == big)       # every step of the larger set after the first step: sized from a small one
+    assert regathered == first_look_incomplete == expect >= 3, (regathered, first_look_incomplete, expect)
+    st = fs.exchange.stats()
+    assert st["gathers"] == n and st["bytes_last"] > 0
+    fs.close()
+    eng.close()
+
+
+def test_exchange_synchronous_gather_and_errors(sm):
+    from siftmetal_amd import _capi, stream as smstream
+    fa = np.stack([blob_frame(320, 240, i) for i in range(2)])
+    eng = sm.Engine(320, 240, n_octaves=3, max_batch=2)
+    k, kc, d, dc = eng.detect_describe_batch(fa)
+    fs = smstream.FrameStream(eng, 2, overlap_gather=True, pipeline=1, result_sets=2)
+    with pytest.raises(_capi.SiftmiError):
+        fs.all_gather()                                         # nothing submitted yet
+    da = smstream.DeviceFrames(fa)
+    for _ in range(3):
+        fs.run(da)
+        fs.all_gather(synchronous=True)                          # sized from this step's own totals: complete at once
+        g = fs.exchange.result_host(back=0)
+        assert g["complete"] and g["records_per_rank"] == (len(k), len(d))
+        assert g["keypoints"][0].tobytes() == k.tobytes() and g["descriptors"][0].tobytes() == d.tobytes()
+    with pytest.raises(_capi.SiftmiError):
+        fs.all_gather()                                         # the same step twice
+    assert fs.exchange.finish() == (0, 0)
+    fs.close()
+    eng.close()
+
+
+def _run_c_host(tmp_path, mode, sets, steps, W=640, H=480, n_oct=3):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "c", "stream_pipeline")
+    assert os.path.exists(exe), "tests/c/stream_pipeline not built (__graft_entry__.build())"
+    fin, fout = str(tmp_path / "frames.bin"), str(tmp_path / "out.bin")
+    np.concatenate(sets).tofile(fin)
+    F = sets[0].shape[0]
+    p = subprocess.run([exe, str(W), str(H), str(n_oct), str(F), str(len(sets)), str(steps), mode, fin, fout],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stderr.decode()[-2000:])
+    raw = open(fout, "rb").read()
+    out, pos = [], 0
+    from siftmetal_amd import _capi
+    while pos < len(raw):
+        step = int(np.frombuffer(raw, np.int64, 1, pos)[0]); pos += 8
+        nk, nd, flags, nc = (int(v) for v in np.frombuffer(raw, np.int32, 4, pos)); pos += 16
+        counts = np.frombuffer(raw, np.int32, nc, pos).reshape(2, F, n_oct); pos += 4 * nc
+        kp = np.frombuffer(raw, _capi.keypoint_dtype, nk, pos); pos += 44 * nk
+        ds = np.frombuffer(raw, _capi.descriptor_dtype, nd, pos); pos += 136 * nd
+        out.append((step, flags, counts, kp, ds))
+    return out, p.stdout.decode()
+
+
+@pytest.mark.parametrize("mode", ["device", "host", "device+exchange", "host+exchange"])
+def test_c_host_stream_two_steps_in_flight_equal_host_api(sm, tmp_path, mode):
+    """tests/c/stream_pipeline.c: a plain C program (no Python, no torch, no HIP headers) drives the frame stream through the C
+    ABI alone -- two steps in flight, frames resident in HBM or fed from ONE page-locked buffer that is refilled as soon as
+    siftmi_stream_wait_upload allows, every step read on the host one step late, optionally the RCCL exchange gathered every
+    step and compared with the step's own results inside the program.  Its per-step output must be byte-identical to the host
+    API's results for that step's frames (what test_frame_stream_two_steps_in_flight... checks through the Python binding)."""
+    sets = [np.stack([blob_frame(640, 480, 20 * j + i, n_blobs=150 + 100 * j) for i in range(4)]) for j in range(3)]
+    eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
+    want = [eng.detect_describe_batch(f) for f in sets]
+    steps = 9
+    out, stdout = _run_c_host(tmp_path, mode, sets, steps)
+    assert [o[0] for o in out] == list(range(steps))
+    for step, flags, counts, kp, ds in out:
+        k, kc, d, dc = want[step % 3]
+        assert flags == 0 and kp.tobytes() == k.tobytes() and ds.tobytes() == d.tobytes(), step
+        assert np.array_equal(counts[0], kc) and np.array_equal(counts[1], dc), step
+    assert "ok %d steps" % steps in stdout
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# known answers that need no restatement of the sample loops (tests/test_oracle_transcription.py asserts the same on the oracle)
+
+@pytest.mark.parametrize("ax,ay", [(2.0, 1.0), (-1.0, 3.0), (1.0, -2.5), (-3.0, -1.0), (0.0, 1.0), (1.0, 0.0)])
+def test_known_answer_linear_ramp_hip(sm, ax, ay):
+    """A linear ramp has one gradient direction phi = atan2(dx, dy) (the reference's argument order): theta must be exactly the
+    angle of orientation bin round(36 phi / 2 pi), and every descriptor cell may hold mass only in the two bins around
+    (phi - theta) 8 / 2 pi, split (1 - frac) : frac, with point-symmetric cell weights -- computed in float64 from the ramp's
+    slope, not from any restatement of the kernels."""
+    from tests import test_oracle_transcription as tk
+    w, h = 256, 192
+    img = tk.ramp_image(w, h, ax, ay)
+    eng = sm.Engine(w, h, n_octaves=2, keep_descriptor_floats=1)
+    eng.detect(img)
+    _, theta, _, _ = tk.ramp_expectation(ax, ay)
+    kps = np.concatenate([tk.ramp_keypoint(w, h, o, eng.octave_size(o)[2], sm.keypoint_dtype) for o in range(2)])
+    d, dc = eng.describe(kps, np.array([1, 1], np.int32))
+    assert dc.tolist() == [1, 1]
+    for o in range(2):
+        ori = eng.orientations(o)
+        assert len(ori) == 1 and ori["count"][0] == 1
+        assert tk.ang_diff(ori["orientations"][0, 0], theta) <= 1e-6, (ori["orientations"][0, 0], theta)
+        assert d["theta"][o] == ori["orientations"][0, 0]
+        tk.check_ramp_descriptor(eng.descriptor_floats(o)[0], d["features"][o].astype(np.int32), ax, ay)
+    eng.close()
+
+
+def test_known_answer_transposed_image_hip(sm, butterfly_bgra):
+    """Transposing the image maps the gradient angle phi -> pi/2 - phi: theta -> pi/2 - theta and the descriptor is the known
+    permutation cell (x, y) -> (3 - x, y), bin k -> (8 - k) mod 8.  Pins cell order, bin direction and the sense of the window
+    rotation on the HIP path with no reference to the oracle."""
+    from tests import test_oracle_transcription as tk
+    img = butterfly_bgra
+    h, w = img.shape[:2]
+    ea = sm.Engine(w, h, n_octaves=4, keep_descriptor_floats=1)
+    eb = sm.Engine(h, w, n_octaves=4, keep_descriptor_floats=1)
+    ka, kca = ea.detect(img)
+    da, dca = ea.describe(ka, kca)
+    eb.detect(np.ascontiguousarray(img.transpose(1, 0, 2)))
+    kt = tk.transposed_keypoints(ka)
+    db, dcb = eb.describe(kt, kca)
+    n = good = n_desc = 0
+    pa = pb = 0
+    for o in range(4):
+        oa, ob = ea.orientations(o), eb.orientations(o)
+        fa, fb = ea.descriptor_floats(o), eb.descriptor_floats(o)
+        ga, gb = da[pa:pa + dca[o]], db[pb:pb + dcb[o]]
+        pa += dca[o]; pb += dcb[o]
+        assert np.array_equal(oa["count"] >= 0, ob["count"] >= 0)                 # the border filter is symmetric in x and y
+        same = (oa["count"] == ob["count"]) & (oa["count"] > 0)
+        assert same.sum() >= 0.97 * (oa["count"] > 0).sum()
+        for k in np.nonzero(same)[0]:
+            ia, ib = np.nonzero(ga["keypoint"] == k)[0], np.nonzero(gb["keypoint"] == k)[0]
+            for i in ia:
+                want_t = (np.pi / 2 - float(ga["theta"][i])) % (2 * np.pi)
+                dt = tk.ang_diff(want_t, gb["theta"][ib])
+                j = ib[int(np.argmin(dt))]
+                n += 1
+                if dt.min() <= 2e-3:
+                    good += 1
+                    want = tk.transpose_descriptor(fa[i])
+                    assert np.sqrt(((want.astype(np.float64) - fb[j]) ** 2).sum()) <= 5e-3, (o, k)
+                    assert np.abs(tk.transpose_descriptor(ga["features"][i].astype(np.int32)) - gb["features"][j].astype(np.int32)).max() <= 3
+                    n_desc += 1
+    assert n > 1300 and good >= 0.97 * n and n_desc == good, (good, n)
+    ea.close(); eb.close()
 
 
 def test_bench_line_contract():
