@@ -602,26 +602,23 @@ __global__ __launch_bounds__(1024) void kp_row_sort_small_kernel(PyramidDesc P, 
 // Histogram accumulation in 64-bit fixed point.  Measured on MI355X (tools/ubench/ubench_lds_atomic.hip):
 // the native LDS float atomic ds_add_f32 costs ~177 cycles per wave-instruction, ds_add_u64 ~6.  All
 // histogram contributions are non-negative and a bin total stays below 2^10 (<= ~1200 samples x
-// |gradient| <= 0.71), so value * 2^40 accumulated in u64 is exact to 2^-40 per add, order-independent
-// (bit-reproducible) and closer to the real-number sum than the reference's sequential f32 sum; the
-// difference to the oracle is its own f32 rounding (~1e-6 relative), inside the stated tolerances.
-constexpr float FIX40 = 1099511627776.0f;             // 2^40
+// |gradient| <= 0.71), so fixed-point sums in u64 are order-independent (bit-reproducible) and closer to the
+// real-number sum than the reference's sequential f32 sum; the difference to the oracle is its own f32
+// rounding (~1e-6 relative), inside the stated tolerances.
 #ifndef SIFTMI_LEAN_ATAN
 #define SIFTMI_LEAN_ATAN 1
 #endif
-// x = c * 2^40 (exact scaling) to a 64-bit integer, truncating; there is no f32 -> u64 instruction, so two 32-bit
-// conversions.  (Measured and not kept: adding 2^52 in double and masking the mantissa -- 3 VALU instead of 5, but the
-// f64 convert / add issue slower: describe 9.76 against 9.62 ms per dense step.)
-__device__ __forceinline__ unsigned long long fix_of_scaled(float x) {
-    const unsigned hi = (unsigned)(x * 2.3283064365386963e-10f);          // trunc(x / 2^32), < 2^18
-    const float rem = fmaf(-(float)hi, 4294967296.0f, x);                 // exact
-    return ((unsigned long long)hi << 32) | (unsigned)rem;
-}
-__device__ __forceinline__ unsigned long long to_fix40(float c) { return fix_of_scaled(c * FIX40); }
-__device__ __forceinline__ float from_fix40(unsigned long long v) { return (float)v * (1.0f / FIX40); }
-// to_fix40(p * value) with the power-of-two scaling hoisted out of the per-corner code: v40 = value * 2^40 is exact, so
-// p * v40 carries the significand of p * value -- the same 64-bit result, one multiply fewer per contribution.
-__device__ __forceinline__ unsigned long long fix40_product(float p, float v40) { return fix_of_scaled(p * v40); }
+// (Rounds 1-2 accumulated value * 2^40: no f32 -> u64 instruction exists, so every contribution took two 32-bit conversions,
+// 6 VALU with the scaling.  A double add of 2^52 and a mantissa mask was 3 VALU but issued slower.)
+// The sample loops of the orientation and descriptor kernels accumulate in units of 2^-32.  A
+// contribution is value x weight <= 0.71 for pixel values in [0, 1] (|gradient| <= sqrt(2) / 2), so c * 2^32 fits ONE
+// v_cvt_u32_f32 (which saturates instead of wrapping for out-of-range float input) and the 64-bit add takes it zero-extended:
+// 2 VALU per contribution (fma with the +0.5 that makes the conversion round to nearest, convert) against 6 for the 2^40 form
+// -- the descriptor loop converts 8 values per sample.  Resolution 2.3e-10 per contribution, unbiased: a bin of a few hundred
+// contributions carries ~2e-9 of absolute error against bin totals of 0.01 ... 30, still two orders below the f32 sums of
+// the reference.  Bin totals stay below 2^10, i.e. 2^42 here.
+__device__ __forceinline__ unsigned long long fix32_product(float p, float v32) { return (unsigned long long)(unsigned)fmaf(p, v32, 0.5f); }
+__device__ __forceinline__ float from_fix32(unsigned long long v) { return (float)v * 2.3283064365386963e-10f; }
 
 // atan2(y, x) of finite arguments for the sample loops (their VALU count is the limit of the orientation and descriptor
 // kernels; the library atan2f is 38 of it, with exponent juggling for a correctly scaled quotient and inf / nan cases that
@@ -652,6 +649,32 @@ __device__ __forceinline__ float atan2_lean(float y, float x) {
 #endif
 }
 
+// Descriptor orientation bin of a gradient that has already been rotated into the keypoint's frame: 8 atan2(y, x) / 2 pi taken
+// into [0, 8].  The reference computes atan2 of the raw gradient, subtracts theta, wraps with two while loops and scales
+// (SIFTDescriptor.metal:203-213); rotating the two gradient components by -theta first (4 VALU) gives the same angle and lets
+// the octant reduction of atan2_lean deliver the BIN directly: the polynomial's coefficients carry the factor 4 / pi, the three
+// reflections are exact (2 - r, 4 - r, 8 - r), and the subtraction, both wrap loops and the scaling disappear (~38 -> ~29
+// VALU).  The angle differs from the reference's by the rounding of the rotation (~1e-7 rad): the trilinear weights are
+// continuous in the bin, so that moves 1e-7 of a sample's weight between neighbouring bins.  octant_bin(0, 0) = 0.
+__device__ __forceinline__ float octant_bin(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
+    const float s = t * t;
+    float q = 3.338654274e-03f;                           // atan2_lean's coefficients x 4 / pi (tools/fit_atan.py)
+    q = fmaf(q, s, -1.926696758e-02f);
+    q = fmaf(q, s, 5.235734632e-02f);
+    q = fmaf(q, s, -9.379525972e-02f);
+    q = fmaf(q, s, 1.346312058e-01f);
+    q = fmaf(q, s, -1.806213739e-01f);
+    q = fmaf(q, s, 2.545256334e-01f);
+    q = fmaf(q, s, -4.244087546e-01f);
+    float r = t * fmaf(s, q, 1.27323954473516268f);        // 4 / pi atan(t), in [0, 1]
+    r = ay > ax ? 2.0f - r : r;
+    r = x < 0.0f ? 4.0f - r : r;
+    return y < 0.0f ? 8.0f - r : r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gradient on demand: SIFTGradient.metal:15-39 (atan2(tx, ty) -- argument order as in the
 // reference -- and |grad| of central differences, mirror edges); outside the image -> (0, 0).
@@ -676,6 +699,10 @@ __device__ __forceinline__ LayerView layer_view(const float *g, int w, int h) {
 }
 __device__ __forceinline__ float layer_ld(const LayerView &v, int byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(v.rsrc, byte_off, 0, 0));
+}
+// the same with a wave-uniform addend in an SGPR (a row pitch): no vector add for the rows above and below
+__device__ __forceinline__ float layer_ld_s(const LayerView &v, int byte_off, int sgpr_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(v.rsrc, byte_off, sgpr_off, 0));
 }
 template <bool FAST_SQRT = false>
 __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, float &theta, float &mag) {
@@ -703,7 +730,7 @@ __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, 
 // ------------------------------------------------------------------------------------------------
 // Orientation: SIFTOctave.getKeypointOrientations (SIFTOctave.swift:290-382) + SIFTOrientation.metal.
 // One wavefront per keypoint; the (2r+1)^2 window is strided over the 64 lanes into a 36-bin LDS
-// histogram (u64 fixed point, see to_fix40); smoothing / peak search run on lanes 0..35 with shuffles.
+// histogram (u64 fixed point, see fix32_product); smoothing / peak search run on lanes 0..35 with shuffles.
 // ori_count[k] = -1 when the host-side border filter of the reference rejects the keypoint.
 __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectParams prm,
                                                          const KeypointRec *__restrict__ kps, const int32_t *__restrict__ kp_count,
@@ -763,7 +790,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
                 if (bin < 0) bin += ORI_BINS;
                 if (bin >= ORI_BINS) bin -= ORI_BINS;
                 const float m = wgt * magnitude;
-                atomicAdd(&hist[bin], to_fix40(m));
+                atomicAdd(&hist[bin], fix32_product(m, 4294967296.0f));
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -772,7 +799,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
         unsigned long long hsum = hist0[li];
 #pragma unroll
         for (int c = 1; c < OCOPY; c++) hsum += hist0[c * OSTRIDE + li];
-        float hv = from_fix40(hsum);
+        float hv = from_fix32(hsum);
         const int lm = (li + ORI_BINS - 1) % ORI_BINS, lp = (li + 1) % ORI_BINS;
         for (int it = 0; it < prm.ori_smoothing; it++) {               // :67-84
             const float h0 = __shfl(hv, lm), h2 = __shfl(hv, lp);
@@ -841,7 +868,7 @@ __global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P,
 // ------------------------------------------------------------------------------------------------
 // Descriptor: SIFTOctave.getDescriptors (SIFTOctave.swift:384-492) + SIFTDescriptor.metal:15-237.
 // One wavefront per (keypoint, theta); the (2R+1)^2 rotated window is strided over the lanes and
-// scattered trilinearly into a 4x4x8 LDS histogram (u64 fixed point, see to_fix40); the two L2
+// scattered trilinearly into a 4x4x8 LDS histogram (u64 fixed point, see fix32_product); the two L2
 // normalisations are wave reductions.  Samples whose truncated coordinate leaves the image contribute nothing (the
 // reference's behaviour there is undefined).
 // Float note.  Per sample the reference divides by histogramWidth twice, calls exp and sqrt.  Metal compiles those with
@@ -866,16 +893,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
                                                         float *__restrict__ desc_f32 /* may be null */) {
-    // NCOPY private copies of the 4x4x8 histogram per wave (copy = lane % NCOPY): neighbouring lanes
-    // take neighbouring samples, which mostly fall into the same cell and bin, and same-address lanes
-    // of one ds_add_u64 serialise (6 cycles distinct, 26 at 4 lanes per address).  u64 fixed point: see to_fix40.
-    // Measured and not kept: padding the copies to 129 u64 apart (the PMC run on dense frames shows 72 % of this kernel's LDS
-    // cycles as bank conflicts) and 8 copies instead of 4 -- describe went 10.85 -> 11.1 / 12.7 ms per dense step: the
-    // conflicts counted are the atomics' own same-bank serialisation across the 8 orientation bins of one cell, which the
-    // pitch of the copies does not change.
-    constexpr int NCOPY = SIFTMI_DESC_NCOPY, CSTRIDE = DESC_N;
+    // NCOPY private copies of the 4x4x8 histogram per wave (copy = lane % NCOPY): neighbouring lanes take neighbouring samples,
+    // which mostly fall into the same cell and bin, and same-address lanes of one ds_add_u64 serialise (6 cycles distinct, 26
+    // at 4 lanes per address).  The copies of a bin are INTERLEAVED (u64 index = slot * NCOPY + copy, round 3): four
+    // neighbouring lanes that hit the same bin then touch four neighbouring banks.  (Rounds 1-2 kept the copies 128 u64 =
+    // 1024 B apart -- the same bank for every copy of a bin, so the copies removed the same-address serialisation and put a
+    // 4-way bank conflict in its place: 72 % of the kernel's LDS cycles in the PMC run.  129 u64 apart cost more address
+    // arithmetic than it saved.)  u64 fixed point: see fix32_product.
+    constexpr int NCOPY = SIFTMI_DESC_NCOPY;
     constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
-    __shared__ unsigned long long patch_all[4][NCOPY * CSTRIDE];
+    __shared__ unsigned long long patch_all[4][NCOPY * DESC_N];
     __shared__ int col_start_all[4][MAXCOL + 1];
     __shared__ short col_lo_all[4][MAXCOL];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -883,7 +910,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
     const int lidx = COOP ? (int)threadIdx.x : lane;
     unsigned long long *patch0 = patch_all[hw_];
-    unsigned long long *patch = patch0 + (lane & (NCOPY - 1)) * CSTRIDE;
+    unsigned long long *patch = patch0 + (lane & (NCOPY - 1));           // this lane's copy; bin slot k sits at patch[k * NCOPY]
     int *col_start = col_start_all[wv];
     short *col_lo = col_lo_all[wv];
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
@@ -899,11 +926,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
         const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // SIFTOctave.swift:417-418
         const LayerView g = layer_view(layer_ptr(P, frame, o, kp.scale), w, h);
         const float px = (float)absoluteX / delta, py = (float)absoluteY / delta;   // metal :140-141
-        const int d = 4, bins = 8;
-        const float tau = 2.0f * SIFTMI_PI_F;
+        const int d = 4;
         const float cosT = cosf(theta), sinT = sinf(theta);
-        const float binsPerRadian = (float)bins / tau;
-        const float exponentDenominator = (float)(d * d) * 0.5f;
         const float interval = (float)kp.scale + kp.sub_scale;
         const float intervals = (float)prm.desc_scales_per_octave;
         const float sigma = 1.6f;
@@ -911,12 +935,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
         const float histogramWidth = 3.0f * sc;
         const float inv_hw = 1.0f / histogramWidth;
         const int radius = (int)(histogramWidth * sqrtf(2.0f) * ((float)d + 1.0f) * 0.5f + 0.5f);
+        // per descriptor, hoisted out of the sample loop (float note above): the rotation with 1 / histogramWidth folded in
+        const float cs = cosT * inv_hw, sn = sinT * inv_hw;
+        // px, py are multiples of 2^-15 well below 2^22, so px + j is exact and ushort2(px + j, ...) truncates to (int)px + j
+        // wherever px + j >= 0: integer sample coordinates, no conversions in the loop
+        const int ipx = (int)px, ipy = (int)py;
+        // the whole window and the +-1 neighbours of its samples lie inside the image: no mirror, no range test per sample
+        const bool interior = ipx - radius >= 1 && ipx + radius <= w - 2 && ipy - radius >= 1 && ipy + radius <= h - 2;
 
         if (COOP) {
             __syncthreads();                                                          // wave 0 is done reading the previous descriptor's bins
-            for (int c = threadIdx.x; c < NCOPY * CSTRIDE; c += 256) patch0[c] = 0ull;
+            for (int c = threadIdx.x; c < NCOPY * DESC_N; c += 256) patch0[c] = 0ull;
         } else {
-            for (int c = lane; c < NCOPY * CSTRIDE; c += 64) patch0[c] = 0ull;             // all copies (contiguous)
+            for (int c = lane; c < NCOPY * DESC_N; c += 64) patch0[c] = 0ull;             // all copies (contiguous)
         }
         const int side = 2 * radius + 1;
 
@@ -967,71 +998,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
         if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // bins cleared (COOP: by all four waves); column table of this wave written
         __threadfence_block();
 
-        int cur = 0;                                                       // window row of this lane's current sample
-        if (compact && lidx < total) {                                     // binary search once, then only advance
-            int lo_c = 0, hi_c = side - 1;                                 // last row whose start <= lidx
-            while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= lidx) lo_c = mid; else hi_c = mid - 1; }
-            cur = lo_c;
-        }
-        int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
-        for (int idx = lidx; idx < total; idx += STRIDE) {
-            int j, i;                                                      // j: x offset (inner), i: y offset (outer)
-            if (compact) {
-                while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty rows have equal starts
-                i = cur - radius;
-                j = (int)col_lo[cur] + (idx - cur_start);
+        // One sample (j = x offset, i = y offset) of the window: SIFTDescriptor.metal:197-222.  INTERIOR (wave-uniform, almost
+        // every descriptor): the sample and its four neighbours are inside the image, so the gradient is four loads at one
+        // 32-bit offset (the rows above and below through an SGPR addend) and there is no per-sample range test or mirror.
+        auto sample = [&](auto interior_tag, int j, int i) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+            const float fj = (float)j, fi = (float)i;
+            const float rx = fmaf(fj, cs, -(fi * sn));                     // (j cosT - i sinT) / histogramWidth
+            const float ry = fmaf(fj, sn, fi * cs);                        // (j sinT + i cosT) / histogramWidth
+            const float bx = rx + 1.5f, by = ry + 1.5f;                    // + d / 2 - 0.5
+            // every trilinear corner of this sample lies outside the 4x4 grid (addValue :66-68 drops all 8 contributions)
+            if (bx <= -1.0f || bx >= 4.0f || by <= -1.0f || by >= 4.0f) return;
+            float dx, dy;                                                  // central differences, not yet halved
+            if (INTERIOR) {
+                const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
+                dx = layer_ld_s(g, c + 8, g.pitch) - layer_ld_s(g, c, g.pitch);
+                dy = layer_ld_s(g, c + 4, 2 * g.pitch) - layer_ld(g, c + 4);
             } else {
-                const int ii = idx / side;
-                i = ii - radius; j = idx - ii * side - radius;
+                // ushort2(px + j, py + i): truncation toward zero, (-1, 0) -> 0; negative: no texel
+                const float fx = px + fj, fy = py + fi;
+                float tx = 0.0f, ty = 0.0f;
+                const int gx = (int)fx, gy = (int)fy;
+                if (fx > -1.0f && fy > -1.0f && gx < w && gy < h) {        // (int) of a huge float is >= w: outside -> gradient (0, 0)
+                    const int mxm = symm(gx - 1, w), mxp = symm(gx + 1, w), mym = symm(gy - 1, h), myp = symm(gy + 1, h);
+                    auto rd = [&](int x, int y) -> float { return (x < 0 || y < 0 || x >= w || y >= h) ? 0.0f : g.g[(size_t)y * w + x]; };
+                    tx = rd(mxp, gy) - rd(mxm, gy);
+                    ty = rd(gx, myp) - rd(gx, mym);
+                }
+                dx = tx; dy = ty;
             }
-            const float rx = ((float)j * cosT - (float)i * sinT) * inv_hw;         // "/ histogramWidth" in the reference: see the float note above
-            const float ry = ((float)j * sinT + (float)i * cosT) * inv_hw;
-            const float bx = rx + (float)(d / 2) - 0.5f;
-            const float by = ry + (float)(d / 2) - 0.5f;
-            // every trilinear corner of this sample lies outside the 4x4 grid (addValue :66-68 drops
-            // all 8 contributions): nothing to add
-            if (bx <= -1.0f || bx >= 4.0f || by <= -1.0f || by >= 4.0f) continue;
-            const float fx = px + (float)j, fy = py + (float)i;                    // ushort2(px + j, py + i): truncation; (-1, 0) -> 0
-            float gth = 0.0f, gm = 0.0f;
-            if (fx > -1.0f && fy > -1.0f) gradient_at<true>(g, (int)fx, (int)fy, gth, gm);   // (int) of a huge float is >= w: outside
-            float orientation = gth - theta;
-            while (orientation < 0.0f) orientation += tau;
-            while (orientation >= tau) orientation -= tau;
-            const float bin = orientation * binsPerRadian;
-            const float exponentNumerator = rx * rx + ry * ry;
-            const float wgt = __expf(-exponentNumerator / exponentDenominator);
-            const float value = gm * wgt;
+            // gradient (tx, ty) = (dx, dy) / 2 (SIFTGradient.metal:31-32), angle atan2(tx, ty), orientation = angle - theta: the
+            // vector (x = ty, y = tx) rotated by -theta; its direction does not depend on the factor 1/2
+            const float xr = fmaf(dy, cosT, dx * sinT), yr = fmaf(dx, cosT, -(dy * sinT));
+            const float bin = octant_bin(yr, xr);                          // in [0, 8]
+            // value = |gradient| exp(-(rx^2 + ry^2) / 8) in units of 2^-32: |gradient| = sqrt(dx^2 + dy^2) / 2
+            // (the factor -1/8 is a power of two: folding it into log2(e) gives the bits of __expf(-(rx^2 + ry^2) / 8))
+            const float wgt = __builtin_amdgcn_exp2f(fmaf(rx, rx, ry * ry) * (-0.125f * 1.44269504088896341f));
+            const float v32 = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * (wgt * 2147483648.0f);
             {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
                 // and bin wrap (:59-79); here one test per cell corner, the two orientation bins wrapped once (bin lies in
-                // [0, 8]: floor / ceil can reach 8, never go negative).  Same products in the same order.
+                // [0, 8]: floor can reach 8, never go negative).
                 // The "upper" corner is floor + 1 here, not ceil: they differ only when the coordinate is an integer, and then
                 // the upper corner's weight is exactly 0 -- it adds 0 whichever cell or bin it names.
                 const float flx = floorf(bx), fly = floorf(by), flb = floorf(bin);
                 const int cax = (int)flx, cay = (int)fly;
-                const int cbx = cax + 1, ccy = cay + 1;
                 const int ba = (int)flb & 7, bb = ((int)flb + 1) & 7;
                 const float iMax = bx - flx, iMin = 1.0f - iMax;
                 const float jMax = by - fly, jMin = 1.0f - jMax;
                 const float bMax = bin - flb, bMin = 1.0f - bMax;
-                const bool xa = (unsigned)cax < 4u, xb = (unsigned)cbx < 4u, ya = (unsigned)cay < 4u, yb = (unsigned)ccy < 4u;
-                const float v40 = value * FIX40;
-                unsigned long long *pa = patch + ba, *pb = patch + bb;
-                if (xa && ya) { const float wxy = iMin * jMin; const int c = cay * 32 + cax * 8;
-                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
-                if (xb && ya) { const float wxy = iMax * jMin; const int c = cay * 32 + cbx * 8;
-                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
-                if (xb && yb) { const float wxy = iMax * jMax; const int c = ccy * 32 + cbx * 8;
-                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
-                if (xa && yb) { const float wxy = iMin * jMax; const int c = ccy * 32 + cax * 8;
-                                atomicAdd(pa + c, fix40_product(wxy * bMin, v40)); atomicAdd(pb + c, fix40_product(wxy * bMax, v40)); }
+                const bool xa = (unsigned)cax < 4u, xb = (unsigned)(cax + 1) < 4u, ya = (unsigned)cay < 4u, yb = (unsigned)(cay + 1) < 4u;
+                const float va = bMin * v32, vb = bMax * v32;              // the value's share of either orientation bin
+                const int c00 = (cay * 32 + cax * 8) * NCOPY;              // u64 index of cell (cax, cay), bin 0, copy 0
+                unsigned long long *pa = patch + c00 + ba * NCOPY, *pb = patch + c00 + bb * NCOPY;
+                if (xa && ya) { const float wxy = iMin * jMin; atomicAdd(pa, fix32_product(wxy, va)); atomicAdd(pb, fix32_product(wxy, vb)); }
+                if (xb && ya) { const float wxy = iMax * jMin; atomicAdd(pa + 8 * NCOPY, fix32_product(wxy, va)); atomicAdd(pb + 8 * NCOPY, fix32_product(wxy, vb)); }
+                if (xb && yb) { const float wxy = iMax * jMax; atomicAdd(pa + 40 * NCOPY, fix32_product(wxy, va)); atomicAdd(pb + 40 * NCOPY, fix32_product(wxy, vb)); }
+                if (xa && yb) { const float wxy = iMin * jMax; atomicAdd(pa + 32 * NCOPY, fix32_product(wxy, va)); atomicAdd(pb + 32 * NCOPY, fix32_product(wxy, vb)); }
             }
-        }
+        };
+        auto walk = [&](auto interior_tag) {
+            int cur = 0;                                                   // window row of this lane's current sample
+            if (compact && lidx < total) {                                 // binary search once, then only advance
+                int lo_c = 0, hi_c = side - 1;                             // last row whose start <= lidx
+                while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= lidx) lo_c = mid; else hi_c = mid - 1; }
+                cur = lo_c;
+            }
+            int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
+            for (int idx = lidx; idx < total; idx += STRIDE) {
+                int j, i;                                                  // j: x offset (inner), i: y offset (outer)
+                if (compact) {
+                    while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty rows have equal starts
+                    i = cur - radius;
+                    j = (int)col_lo[cur] + (idx - cur_start);
+                } else {
+                    const int ii = idx / side;
+                    i = ii - radius; j = idx - ii * side - radius;
+                }
+                sample(interior_tag, j, i);
+            }
+        };
+        if (interior) walk(std::true_type{}); else walk(std::false_type{});
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
         __threadfence_block();
-        unsigned long long a0 = patch0[lane], a1 = patch0[64 + lane];
+        unsigned long long a0 = 0ull, a1 = 0ull;                           // bins lane and lane + 64: their NCOPY copies are adjacent
 #pragma unroll
-        for (int c = 1; c < NCOPY; c++) { a0 += patch0[c * CSTRIDE + lane]; a1 += patch0[c * CSTRIDE + 64 + lane]; }
-        float f0 = from_fix40(a0), f1 = from_fix40(a1);
+        for (int c = 0; c < NCOPY; c++) { a0 += patch0[lane * NCOPY + c]; a1 += patch0[(64 + lane) * NCOPY + c]; }
+        float f0 = from_fix32(a0), f1 = from_fix32(a1);
         {   // normalise -> clamp 0.2 -> normalise (:15-39, :224-227)
             float dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));
             f0 *= dn; f1 *= dn;

@@ -51,6 +51,7 @@ def _image(name, size, butterfly_bgra):
 # default: small launches -> tile blur, full extrema scan.  march_skip: every layer through the marching blur, which flags
 # the rows that can hold a candidate, and the extrema scan skips the others (the large-launch path).  march_count: the
 # marching blur with the flags off (count_raw_extrema = 1).
+EXACT_COUNTS = {"orientation_count_mismatch": 0, "descriptors_unmatched": 0}
 MODES = {"default": {}, "march_skip": {"blur_march_min_blocks": 1}, "march_count": {"blur_march_min_blocks": 1, "count_raw_extrema": 1}}
 
 
@@ -58,7 +59,9 @@ MODES = {"default": {}, "march_skip": {"blur_march_min_blocks": 1}, "march_count
 @pytest.mark.parametrize("name,size,no,nspo", CASES)
 def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no, nspo, mode):
     img = _image(name, size, butterfly_bgra)
-    parity.check_full_path(sm, img, no, nspo, **MODES[mode])
+    # observed on every one of these fixed cases (gpurun_out/r3/parity_counts.log, round 3): every keypoint gets the same NUMBER of
+    # orientations as the oracle gives it and every descriptor finds its partner -- asserted exactly, not as a budget
+    parity.check_full_path(sm, img, no, nspo, expect=EXACT_COUNTS, **MODES[mode])
 
 
 def test_butterfly_against_ipol_fixtures(sm, butterfly_bgra, ipol):
@@ -650,7 +653,7 @@ def test_1080p_marching_path_stage_by_stage_vs_oracle(sm, butterfly_bgra, which)
     (blur_march_min_blocks = 1): every stage against the oracle, on two benchmark frames and on the dense natural-texture
     frame."""
     img = _natural_1080p(butterfly_bgra) if which == "dense" else blob_frame(1920, 1080, int(which[4:]))
-    rep = parity.check_full_path(sm, img, 4, 3, blur_march_min_blocks=1)
+    rep = parity.check_full_path(sm, img, 4, 3, expect=EXACT_COUNTS, blur_march_min_blocks=1)
     assert rep["keypoints"] > (10000 if which == "dense" else 1500)
 
 

@@ -7,6 +7,12 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--torch" in sys.argv:            # as bench.py: torch (and its bundled HIP runtime) loaded and initialised first
+    sys.argv.remove("--torch")
+    import torch
+    torch.cuda.init()
+    torch.cuda.synchronize()
+    print("torch loaded first:", torch.__version__)
 import __graft_entry__ as ge  # noqa: E402
 
 ge.build()
