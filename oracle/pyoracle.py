@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libsift_oracle.so")
+_LIB = os.environ.get("SIFT_ORACLE_LIB") or os.path.join(_HERE, "libsift_oracle.so")     # SIFT_ORACLE_LIB: the sanitizer build (make asan)
 
 FMT_BGRA8, FMT_GRAY8, FMT_GRAYF32 = 0, 1, 2
 
@@ -33,7 +33,7 @@ assert keypoint_dtype.itemsize == 44 and orientation_dtype.itemsize == 152 and d
 def build(force=False):
     if force or not os.path.exists(_LIB) or \
             os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "sift_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _LIB.endswith("_asan.so") else []))
     return _LIB
 
 

@@ -10,7 +10,6 @@ All compute happens in libsiftmi.so (hand-written HIP for gfx950, C ABI in inclu
 module only binds it.  There is no CPU fallback: importing works anywhere, creating a SIFT object
 without a HIP device raises.
 """
-import atexit
 import ctypes as C
 import weakref
 from dataclasses import dataclass, field
@@ -87,21 +86,7 @@ def _fmt_of(img):
     raise ValueError("image must be HxWx4 uint8 (BGRA, the reference's .bgra8Unorm), HxW uint8 or HxW float32")
 
 
-_interpreter_exiting = False
-
-
-def _mark_exit():
-    global _interpreter_exiting
-    _interpreter_exiting = True
-
-
-atexit.register(_mark_exit)
-
-
 def _free_pinned(addr):
-    # at interpreter teardown the HIP runtime may already be gone: leave the pages to process exit
-    if _interpreter_exiting:
-        return
     try:
         _capi.load().siftmi_host_free(C.c_void_p(addr))
     except Exception:
@@ -118,6 +103,7 @@ def pinned_empty(shape, dtype=np.uint8):
     _capi.check(_capi.load().siftmi_host_alloc(n, C.byref(ptr)))
     block = (C.c_uint8 * n).from_address(ptr.value)      # numpy keeps `block` alive as the base of the array and its views
     block._siftmi_finalizer = weakref.finalize(block, _free_pinned, ptr.value)
+    block._siftmi_finalizer.atexit = False               # at interpreter exit the pages are left to the process teardown (the HIP runtime may be gone)
     return np.frombuffer(block, dtype=np.uint8, count=int(np.prod(shape)) * dtype.itemsize).view(dtype).reshape(shape)
 
 
@@ -188,6 +174,7 @@ class Engine:
 
     # ---- SIFT.getKeypoints / getDescriptors at array level ----
     def detect(self, img, allow_capacity=False):
+        img = np.asarray(img)
         # rows may be strided (a view into a wider buffer: the C ABI takes a row stride); pixels of a row must be contiguous
         if not (img.strides[-1] == img.itemsize and (img.ndim == 2 or img.strides[1] == img.shape[2] * img.itemsize) and img.strides[0] > 0):
             img = np.ascontiguousarray(img)

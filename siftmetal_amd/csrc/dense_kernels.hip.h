@@ -478,7 +478,13 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 // interleave on the banks, and every other access to the ring applies the same XOR.  Measured on 32 x 3840x2160: 2-3.5 %
 // faster for R = 5 ... 10; at R >= 13 its 40 + 8 registers per item no longer fit 128 VGPRs beside the prefetch (spill),
 // so those radii keep 4 outputs per lane.
-template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12)>
+// HPIPE (round 3): the horizontal pass takes its items two at a time and issues both items' LDS reads before the first FMA.
+// Measured on 32 x 3840x2160 (profiles/blur_variants_r03_hpipe.log): R = 5 0.418 -> 0.398 ms, R = 7 0.439 -> 0.428, R = 8
+// 0.454 -> 0.445; nothing at R = 10 and 13 (0.511 / 0.607 either way, also with 168 registers per lane) -- those layers sit at
+// the FMA issue rate three waves per SIMD reach (tools/ubench/ubench_valu: 3.4 / 2.9 / 2.7 cycles per v_fma_f32 at 2 / 4 / 8
+// waves), not at LDS latency.  On for R <= 8.
+template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12),
+          bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */>
 __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                              int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
@@ -664,27 +670,30 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         // horizontal pass, in place (first step: the S + 2R prologue rows; later steps: the S new rows)
         const int hb = st == 0 ? -2 * R : st * S, hn = st == 0 ? S + 2 * R : S;
         if constexpr (H8) {
-#pragma unroll 1
-            for (int item = tid; item < ((DBG & 8) ? 0 : hn * 16); item += G::NTHR) {
+            constexpr int M0 = (RP - R) / 4, M1 = (RP + R + 7) / 4 + 1;
+            static_assert((RP / 4) % 2 == 0, "the first output float4 of a lane must be an even one");
+            // logical float4 m of a lane's segment sits at float4 m ^ (slot & 1): even m at +D, odd m at -D, D = 4 (slot & 1)
+            auto h8_load = [&](int item, float (&v)[4 * (M1 - M0)]) {
                 const int slot = (hb + (item >> 4) + NR) & (NR - 1), c8 = (item & 15) * 8;
-                float *rowp = lds + slot * LW + c8;
-                // logical float4 m of this lane's segment sits at float4 m ^ (slot & 1): even m at +D, odd m at -D, D = 4 (slot & 1)
+                const float *rowp = lds + slot * LW + c8;
                 const int D = x4(slot);
-                constexpr int M0 = (RP - R) / 4, M1 = (RP + R + 7) / 4 + 1;
-                float v[4 * (M1 - M0)];
                 const lds_cv_f32x4 *re = (const lds_cv_f32x4 *)(rowp + D), *ro = (const lds_cv_f32x4 *)(rowp - D);
 #pragma unroll
                 for (int m = M0; m < M1; m++) {
                     const f32x4 tv = (m & 1) ? ro[m] : re[m];
                     v[4 * (m - M0) + 0] = tv.x; v[4 * (m - M0) + 1] = tv.y; v[4 * (m - M0) + 2] = tv.z; v[4 * (m - M0) + 3] = tv.w;
                 }
+            };
+            auto h8_finish = [&](int item, const float (&v)[4 * (M1 - M0)]) {
+                const int slot = (hb + (item >> 4) + NR) & (NR - 1), c8 = (item & 15) * 8;
+                float *rowp = lds + slot * LW + c8;
+                const int D = x4(slot);
                 float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int i = 0; i < G::NT; i++) {
 #pragma unroll
                     for (int k = 0; k < 8; k++) acc[k] = fmaf(tw(i), v[(RP - R - 4 * M0) + k + i], acc[k]);
                 }
-                static_assert((RP / 4) % 2 == 0, "the first output float4 of a lane must be an even one");
                 *reinterpret_cast<float4 *>(rowp + RP + D) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 *reinterpret_cast<float4 *>(rowp + RP + 4 - D) = make_float4(acc[4], acc[5], acc[6], acc[7]);
                 if (ACT) {                                  // max |hb - raw| over this lane's 8 columns = one sub-cell
@@ -693,6 +702,30 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
 #pragma unroll
                     for (int k = 1; k < 8; k++) e = fmaxf(e, fabsf(acc[k] - v[C + k]));
                     ehm(slot, item & 15) = e;
+                }
+            };
+            const int n_items = (DBG & 8) ? 0 : hn * 16;
+            if constexpr (HPIPE) {
+                // Two items per trip, both items' LDS reads issued before the first FMA: the second item's read latency runs
+                // under the first item's 8 (2R + 1) FMAs instead of in front of its own (a row is still read and written by one
+                // wavefront within one trip, so the in-place update stays safe).  Needs ~2 x 32 operand registers: R >= 9 only,
+                // where three workgroups per CU leave 168 VGPRs per lane.
+#pragma unroll 1
+                for (int item = tid; item < n_items; item += 2 * G::NTHR) {
+                    float va[4 * (M1 - M0)], vb[4 * (M1 - M0)];
+                    const int item_b = item + G::NTHR;
+                    const bool has_b = item_b < n_items;             // wave-uniform (n_items is a multiple of 64)
+                    h8_load(item, va);
+                    if (has_b) h8_load(item_b, vb);
+                    h8_finish(item, va);
+                    if (has_b) h8_finish(item_b, vb);
+                }
+            } else {
+#pragma unroll 1
+                for (int item = tid; item < n_items; item += G::NTHR) {
+                    float v[4 * (M1 - M0)];
+                    h8_load(item, v);
+                    h8_finish(item, v);
                 }
             }
         } else {

@@ -771,27 +771,43 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
             const int y = (int)roundf((float)absoluteY / delta);
             const float sigma = kp.sigma / delta;
             const float exponentDenominator = 2.0f * lambda * lambda;
-            // per keypoint: the two reciprocals the sample loop multiplies by (the reference divides per sample; float
-            // note at descriptor_kernel: the weight of a sample moves by 1-2 ulp, the bin it goes to does not depend on it)
-            const float inv_sigma = 1.0f / sigma, neg_inv_den = -1.0f / exponentDenominator;
+            // per keypoint: the reciprocals the sample loop multiplies by (the reference divides per sample; float note at
+            // descriptor_kernel: the weight of a sample moves by 1-2 ulp, the bin it goes to does not depend on it), with
+            // log2(e) folded into the exponent's factor (v_exp_f32 is 2^x)
+            const float inv_sigma = 1.0f / sigma, k_exp = (-1.0f / exponentDenominator) * 1.44269504088896341f;
             const int r = (int)ceilf(3.0f * lambda * sigma);
             const int side = 2 * r + 1, total = side * side;
             const float inv_side = 1.0f / (float)side;                 // idx / side below: idx + 0.5 keeps the quotient >= 0.5 / side off every integer, far more than the float error at idx < 2^20
-            for (int idx = lane; idx < total; idx += 64) {
+            // The host border filter works on the float position, the window is centred on the rounded truncated one (up to two
+            // pixels lower at delta = 0.5): almost every window still has all its samples and their +-1 neighbours inside the
+            // image (wave-uniform test) and takes the gradient as four loads at one offset, without per-sample range tests.
+            const bool interior = x - r >= 1 && x + r <= w - 2 && y - r >= 1 && y + r <= h - 2;
+            auto sample = [&](auto interior_tag, int idx) {
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
                 const int jj = (int)(((float)idx + 0.5f) * inv_side), ii = idx - jj * side;
                 const int j = jj - r, i = ii - r;
                 const float u = (float)i * inv_sigma, v = (float)j * inv_sigma;
-                const float r2 = u * u + v * v;
-                const float wgt = __expf(r2 * neg_inv_den);
+                const float wgt = __builtin_amdgcn_exp2f(fmaf(u, u, v * v) * k_exp);
                 float orientation, magnitude;
-                gradient_at<true>(g, x + i, y + j, orientation, magnitude);
-                const float t = orientation / (2.0f * SIFTMI_PI_F);
-                int bin = (int)roundf(t * (float)ORI_BINS);
+                if (INTERIOR) {
+                    const int c = __mul24(y + j - 1, g.pitch) + ((x + i - 1) << 2);      // texel (x + i - 1, y + j - 1)
+                    const float tx = (layer_ld_s(g, c + 8, g.pitch) - layer_ld_s(g, c, g.pitch)) * 0.5f;
+                    const float ty = (layer_ld_s(g, c + 4, 2 * g.pitch) - layer_ld(g, c + 4)) * 0.5f;
+                    orientation = atan2_lean(tx, ty);
+                    magnitude = __builtin_amdgcn_sqrtf(fmaf(tx, tx, ty * ty));
+                } else {
+                    gradient_at<true>(g, x + i, y + j, orientation, magnitude);
+                }
+                // t = orientation / 2 pi, bin = round(36 t) in the reference: one multiply here.  The product can round
+                // differently from the quotient's only within an ulp of a half-integer, where atan2_lean's own 2.4 ulp already decide.
+                int bin = (int)roundf(orientation * (float)(ORI_BINS / (2.0 * 3.14159265358979323846)));
                 if (bin < 0) bin += ORI_BINS;
                 if (bin >= ORI_BINS) bin -= ORI_BINS;
                 const float m = wgt * magnitude;
                 atomicAdd(&hist[bin], fix32_product(m, 4294967296.0f));
-            }
+            };
+            if (interior) { for (int idx = lane; idx < total; idx += 64) sample(std::true_type{}, idx); }
+            else          { for (int idx = lane; idx < total; idx += 64) sample(std::false_type{}, idx); }
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();

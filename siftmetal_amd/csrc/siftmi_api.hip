@@ -164,9 +164,9 @@ struct siftmi_ctx {
                    kp == o.kp && kp_cap == o.kp_cap && desc == o.desc && desc_cap == o.desc_cap && counts == o.counts && totals == o.totals && st == o.st;
         }
     };
-    // Captured launch sequences, most recently used last; up to GCACHE_MAX call signatures per context, further ones run
-    // with direct launches.  Executable graphs are never destroyed (runtime defect, see drop_graphs()).
-    struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
+    // Captured launch sequences, most recently used last; up to GCACHE_MAX call signatures per context, the least recently
+    // used one is evicted for a new one (retire_exec()).
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec; bool raw_exact; };   // raw_exact: what run_dense_detect decided while the sequence was captured
     std::vector<GraphEntry> gcache;
     std::vector<GraphKey> gseen;               // signatures seen once (not yet captured), oldest first
     static constexpr size_t GCACHE_MAX = 64;
@@ -238,6 +238,8 @@ extern "C" int siftmi_device_count(void) {
     return n;
 }
 
+static void retire_exec(hipGraphExec_t exec);
+
 static void free_ctx(siftmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -249,7 +251,8 @@ static void free_ctx(siftmi_ctx *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    c->gcache.clear();                        // executable graphs are abandoned, not destroyed: see drop_graphs()
+    for (auto &g : c->gcache) retire_exec(g.exec);   // (device idle: synchronised above)
+    c->gcache.clear();
     for (int i = 0; i < MAX_OCT; i++) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -752,16 +755,37 @@ static int run_pack(siftmi_ctx *c, hipStream_t st, int nf, int frame_base, int t
     return SIFTMI_OK;
 }
 
+// Retiring executable graphs.  With the HIP runtime that PyTorch 2.10 bundles (a ROCm 7.0 build, the one a process gets when
+// torch is imported first) hipGraphExecDestroy left the runtime in a state in which a later hipGraphLaunch of ANOTHER
+// executable graph dereferenced a null pointer -- about 1 in 10 runs of tools/fuzz_api.py (600 random operations) segfaulted
+// inside hipGraphLaunch, none in 80 runs without the destroy calls (round 1).  The ROCm 7.2 runtime of the image passes the same
+// sweep with the destroy calls (round 3, profiles/fuzz_api_r03_graph_destroy.log).  So: destroy on a runtime >= 7.2, abandon
+// (leak, a few hundred kB each) on an older one; SIFTMI_GRAPH_DESTROY=0/1 overrides.
+static bool graph_destroy_safe() {
+    static const int safe = [] {
+        if (const char *e = getenv("SIFTMI_GRAPH_DESTROY")) return atoi(e) != 0 ? 1 : 0;
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) return 0;
+        return v >= 70200000 ? 1 : 0;                         // HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+    }();
+    return safe != 0;
+}
+static size_t graph_cache_max() {                             // SIFTMI_GRAPH_CACHE: smaller caches for the eviction tests
+    static const size_t n = [] {
+        const char *e = getenv("SIFTMI_GRAPH_CACHE");
+        const int v = e ? atoi(e) : 0;
+        return (size_t)((v >= 1 && v <= (int)siftmi_ctx::GCACHE_MAX) ? v : (int)siftmi_ctx::GCACHE_MAX);
+    }();
+    return n;
+}
+static void retire_exec(hipGraphExec_t exec) {
+    if (exec && graph_destroy_safe()) (void)hipGraphExecDestroy(exec);
+}
 // captured graphs hold raw pointers into the context's buffers: drop them (device idle) before any such buffer is replaced
-// Executable graphs are never destroyed.  With the HIP runtime of this image (ROCm 7.0 build bundled with PyTorch 2.10)
-// hipGraphExecDestroy leaves the runtime in a state in which a later hipGraphLaunch of ANOTHER executable graph
-// dereferences a null pointer -- about 1 in 10 runs of tools/fuzz_api.py (600 random operations) segfaulted inside
-// hipGraphLaunch, none in 80 runs without the destroy calls.  A context therefore keeps at most GCACHE_MAX captured
-// signatures, runs further ones with direct launches, and abandons (leaks, a few hundred kB each) the graphs it can no
-// longer use: when a buffer they point into is replaced, and when the context is destroyed.
 static void drop_graphs(siftmi_ctx *c) {
     if (c->gcache.empty()) return;
     (void)hipDeviceSynchronize();
+    for (auto &g : c->gcache) retire_exec(g.exec);
     c->gcache.clear();
     c->gseen.clear();
 }
@@ -850,9 +874,17 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
                 c->gcache.erase(c->gcache.begin() + (long)i);
                 c->gcache.push_back(hit);
                 exec = hit.exec;
+                c->raw_exact = hit.raw_exact;                     // a replay does not run the host code that sets it
                 break;
             }
-        if (!exec && seen && c->gcache.size() < siftmi_ctx::GCACHE_MAX) {
+        if (!exec && seen) {
+            if (c->gcache.size() >= graph_cache_max()) {
+                // full: the least recently used signature goes (round 2 stopped capturing for good here, so a context that had
+                // met 64 signatures ran every new one with direct launches)
+                (void)hipDeviceSynchronize();                  // it may still be running
+                retire_exec(c->gcache.front().exec);
+                c->gcache.erase(c->gcache.begin());
+            }
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
@@ -870,7 +902,7 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
                 exec = nullptr;
                 c->graph_failed = true;          // fall through to direct launches, now and later
             } else {
-                c->gcache.push_back(siftmi_ctx::GraphEntry{key, exec});
+                c->gcache.push_back(siftmi_ctx::GraphEntry{key, exec, c->raw_exact});
             }
         }
         if (exec) {

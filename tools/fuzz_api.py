@@ -8,7 +8,11 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
+
+if "--torch" in sys.argv:            # torch first: the process then runs on the HIP runtime torch bundles (ROCm 7.0 build)
+    sys.argv.remove("--torch")
+    import torch
+    torch.cuda.init()
 
 import siftmetal_amd as sm
 from siftmetal_amd import stream as smstream
@@ -20,7 +24,6 @@ def main():
     n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    dev = torch.device("cuda", 0)
     fails = 0
     t0 = time.time()
     for round_ in range(3):
@@ -58,15 +61,17 @@ def main():
             elif kind == "device":
                 F = len(ids)
                 if F not in streams:
-                    streams[F] = smstream.FrameStream(eng, F, device=dev)
+                    streams[F] = smstream.FrameStream(eng, F)
                 fs = streams[F]
                 reps = int(rng.integers(1, 5))
-                d = torch.from_numpy(np.stack([pool[i] for i in ids])).to(dev)
+                d = smstream.DeviceFrames(np.stack([pool[i] for i in ids]))
                 for _ in range(reps):
                     fs.run(d)
                     if rng.random() < 0.5:
-                        torch.cuda.synchronize()
+                        fs.synchronize()
                 r = fs.results_host()
+                fs.synchronize()
+                d.close()
                 check("device batch x%d" % reps, (r["keypoints"], r["counts"][0], r["descriptors"], r["counts"][1]), ids)
             elif kind == "single":
                 i = ids[0]
@@ -120,6 +125,8 @@ def main():
                         print("knife-edge threshold decision(s) differ from the f32 oracle", flush=True)
                 print("%s match %d vs %d: %d matches" % ("ok  " if ok else "FAIL", i, j, len(m)), flush=True)
                 fails += 0 if ok else 1
+        for fs in streams.values():
+            fs.close()
         eng.close()
     print("%d failures, %.0f s" % (fails, time.time() - t0), flush=True)
     return 1 if fails else 0

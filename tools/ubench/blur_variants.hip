@@ -100,6 +100,12 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, H8_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
     VRX(32, 256, 4, true) VRX(32, 256, 3, true) VRX(32, 256, 3, false) VRX(32, 128, 3, true)
+    // round 3: the horizontal pass software-pipelined over two items (HPIPE), 3 workgroups per CU (168 VGPRs)
+#define VRP(S_, CHR_, MINW_, H8_) { using G = RingGeom<R, S_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_ " HPIPE", c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, H8_, true>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
+    VRP(32, 256, 3, true) VRP(32, 256, 2, true)
     // with the extrema activity flags (ACT) as layers 2 ... nspo+1 of the pipeline write them
 #define VRA(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
