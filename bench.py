@@ -401,32 +401,37 @@ def main():
         # transfer of step k+1 runs under the kernels of step k, and step k's results are copied back while k+1 runs
         hpin = sm.pinned_empty(frames_np.shape, np.uint8)
         hpin[...] = frames_np
+        t1 = time.perf_counter()
+        for _ in range(3):
+            _capi.check(_capi.load().siftmi_memcpy(d_frames.ptr, hpin.ctypes.data, hpin.nbytes, 0))
+        h2d_gbs = 3 * hpin.nbytes / (time.perf_counter() - t1) / 1e9
+        ehs = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
+        hs = smstream.FrameStream(ehs, F, device=dev, pipeline=args.pipeline, result_sets=2 * args.pipeline)
         back = args.pipeline                              # read step i - back after launching step i: the upload of step i+1 is
-        for i in range(2 * runner.n_sets + 2):            # then issued while steps i-1 and i still run.  Warm-up: every (staging
-            runner.run_host(hpin)                         # buffer, result set) pairing seen twice (captured, then replayed) and
+        for i in range(2 * hs.n_sets + 2):                # then issued while steps i-1 and i still run.  Warm-up: every (staging
+            hs.run_host(hpin)                             # buffer, result set) pairing seen twice (captured, then replayed) and
             if i >= back:                                 # every result set's page-locked host buffers allocated
-                runner.results_host(back=back, copy=False)
+                hs.results_host(back=back, copy=False)
         dev_sync()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            runner.run_host(hpin)
-            if i >= back:
-                rio = runner.results_host(back=back, copy=False)
-        for b in range(back - 1, -1, -1):
-            rio = runner.results_host(back=b, copy=False)       # views of the stream's page-locked buffers: nothing is allocated in the timed loop
+            hs.run_host(hpin)
+            rio = hs.results_host(back=back, copy=False)  # views of the stream's page-locked buffers: nothing is allocated in the timed loop
         dev_sync()
         ms_ios = (time.perf_counter() - t1) / args.steps * 1e3
         if (rio["n_keypoints"], rio["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]):
             raise SystemExit("bench: host-fed stream results differ from the resident ones")
         out["config"]["host_io_stream"] = {"workload": "the same step through siftmi_stream_submit_host / siftmi_stream_result_host (C ABI): frames in page-locked host memory, "
                                                        "upload of step k+1 under the kernels of step k (copy stream, rotating staging buffers), every step's packed "
-                                                       "keypoints + descriptors copied to page-locked host memory (copy started at submit time)",
+                                                       "keypoints + descriptors copied to page-locked host memory (copy started at submit time) and read %d steps late" % back,
                                            "ms_per_step": round(ms_ios, 4), "Mpixels_per_s": round(F * W * H / ms_ios / 1e3, 1),
-                                           "h2d_bytes_per_step": int(hpin.nbytes), "d2h_bytes_per_step": int(rio["keypoints"].nbytes + rio["descriptors"].nbytes)}
+                                           "h2d_bytes_per_step": int(hpin.nbytes), "d2h_bytes_per_step": int(rio["keypoints"].nbytes + rio["descriptors"].nbytes),
+                                           "synchronous_h2d_GBps": round(h2d_gbs, 1)}
         out["host_io_stream_ms_per_step"] = round(ms_ios, 4)          # SURVEY.md 8d's wording of the metric (PCIe in and out included)
         out["host_io_stream_Mpixels_per_s"] = round(F * W * H / ms_ios / 1e3, 1)
-        log("host i/o through the frame stream: %.3f ms/step (%.0f Mpixels/s)" % (ms_ios, F * W * H / ms_ios / 1e3))
+        log("host i/o through the frame stream: %.3f ms/step (%.0f Mpixels/s); synchronous H2D %.1f GB/s" % (ms_ios, F * W * H / ms_ios / 1e3, h2d_gbs))
         del rio
+        hs.close(); ehs.close()
         sm.pinned_release(hpin)
         # dense natural texture: the same step on 64 mirror-tiled butterfly frames (not sparse synthetic blobs)
         d_dense = smstream.DeviceFrames(make_dense_frames(F), local_rank)

@@ -980,6 +980,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
         int total;
         if (compact) {
             const float Lh = 2.5f * histogramWidth;
+            const float inv_cos = 1.0f / cosT, inv_sin = 1.0f / sinT;      // (unused where the component is ~0)
             int run = 0;
             for (int c0 = 0; c0 < side; c0 += 64) {
                 const int cidx = c0 + lane;
@@ -989,15 +990,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
                     // |j*cosT - yf*sinT| < Lh  and  |j*sinT + yf*cosT| < Lh
                     float a0 = -(float)radius, a1 = (float)radius;
                     if (fabsf(cosT) > 1e-6f) {
-                        const float u = (yf * sinT - Lh) / cosT, v = (yf * sinT + Lh) / cosT;
+                        const float u = (yf * sinT - Lh) * inv_cos, v = (yf * sinT + Lh) * inv_cos;
                         a0 = fmaxf(a0, fminf(u, v)); a1 = fminf(a1, fmaxf(u, v));
                     } else if (fabsf(yf * sinT) >= Lh + 1.0f) { a1 = a0 - 1.0f; }
                     if (fabsf(sinT) > 1e-6f) {
-                        const float u = (-Lh - yf * cosT) / sinT, v = (Lh - yf * cosT) / sinT;
+                        const float u = (-Lh - yf * cosT) * inv_sin, v = (Lh - yf * cosT) * inv_sin;
                         a0 = fmaxf(a0, fminf(u, v)); a1 = fminf(a1, fmaxf(u, v));
                     } else if (fabsf(yf * cosT) >= Lh + 1.0f) { a1 = a0 - 1.0f; }
-                    lo = max(-radius, (int)floorf(a0) - 2);
-                    hi = min(radius, (int)ceilf(a1) + 2);
+                    // a sample qualifies only for a0 < j < a1 (strict), so [floor(a0), ceil(a1)] already holds one column more
+                    // than can qualify on either side -- four orders above the float error of a0 / a1.  (Rounds 1-2 added two
+                    // more per side: 8 % of the walked candidates never passed the exact test below.)
+                    lo = max(-radius, (int)floorf(a0));
+                    hi = min(radius, (int)ceilf(a1));
                 }
                 const int len = max(hi - lo + 1, 0);
                 int incl = len;                                            // inclusive wave prefix sum

@@ -581,7 +581,14 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
     if (c->ow[o] < 3 || c->oh[o] < 3) return SIFTMI_OK;
     // rows per workgroup, a multiple of 3 (the row loop is unrolled 3x); with activity flags one lane per window row
     // fetches the flags, so EH + 2 <= 64, and taller blocks amortise that fetch
-    const int EH = c->act_valid[o] ? 60 : 33;
+    int EH = c->act_valid[o] ? 60 : 33;
+    if (!c->act_valid[o]) {
+        // a frame or two: the scan of a small octave is a handful of workgroups, each walking its 33 rows one dependent row-load
+        // latency after the other (20 us for the 480 x 270 octave of a single 1080p frame).  Fewer rows per workgroup until the
+        // launch has ~1000 of them: the walk gets shorter by the same factor (the two halo rows per workgroup are L2 hits)
+        const long long cols = (c->ow[o] - 2 + EXT_COLS_PER_BLOCK - 1) / EXT_COLS_PER_BLOCK;
+        while (EH > 6 && cols * ((c->oh[o] - 2 + EH - 1) / EH) * nf < 1024) EH -= 3;
+    }
     t_begin(c, SIFTMI_T_EXTREMA);
     dim3 grid((c->ow[o] - 2 + EXT_COLS_PER_BLOCK - 1) / EXT_COLS_PER_BLOCK, (c->oh[o] - 2 + EH - 1) / EH, nf);
     const unsigned char *actp = c->act_valid[o] ? c->d_act + c->act_off[o] : nullptr;
