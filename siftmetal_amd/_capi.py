@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiftmi.so")
+LIB_PATH = os.environ.get("SIFTMI_LIB") or os.path.join(_HERE, "libsiftmi.so")      # SIFTMI_LIB: an experiment build (tools/)
 
 OK, E_BADARG, E_CAPACITY, E_HIP, E_NODEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5, -6
 FMT_BGRA8, FMT_GRAY8, FMT_GRAYF32 = 0, 1, 2

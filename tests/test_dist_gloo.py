@@ -188,3 +188,37 @@ def test_gather_plan_rule_matches_its_statement():
     assert L.siftmi_gather_plan_resolve(C.byref(p), t.ctypes.data, 3, 2000, 249) == 1
     assert p.steps_incomplete == 2
     assert L.siftmi_gather_plan_resolve(None, t.ctypes.data, 3, 0, 0) == _capi.E_BADARG
+
+
+@pytest.mark.timeout(300)
+def test_bench_control_plane_under_torchrun(tmp_path):
+    """bench.py --gpus N uses torch.distributed only as its control plane (gloo on the loopback interface: rank 0's ncclUniqueId
+    to the other ranks, barrier, per-rank times); the data path's RCCL communicator lives in libsiftmi.so.  The same calls under
+    the launcher the driver uses, two ranks on CPU."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import os, torch, torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo")
+        r, n = dist.get_rank(), dist.get_world_size()
+        box = [bytes(range(128)) if r == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        assert box[0] == bytes(range(128)) and n == int(os.environ["WORLD_SIZE"])
+        t = torch.tensor([1.0 + r], dtype=torch.float64)
+        g = [torch.zeros(1, dtype=torch.float64) for _ in range(n)]
+        dist.all_gather(g, t)
+        assert [float(x) for x in g] == [1.0 + i for i in range(n)]
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank %d of %d ok" % (r, n), flush=True)
+    """)
+    script = tmp_path / "control_plane.py"
+    script.write_text(code)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    out = p.stdout.decode()
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert "rank 0 of 2 ok" in out and "rank 1 of 2 ok" in out

@@ -832,6 +832,76 @@ def test_exchange_synchronous_gather_and_errors(sm):
     eng.close()
 
 
+def test_stream_api_contract_and_errors(sm):
+    """siftmi_stream_*: argument checks, the validity window of result sets, wait_upload / wait_consumed, host views that stay
+    valid until their set is reused, overflow reported through the host view, gray-f32 streams, row / frame strides on host frames."""
+    import ctypes as C
+    from siftmetal_amd import _capi, stream as smstream
+    L = _capi.load()
+    eng = sm.Engine(320, 240, n_octaves=3, max_batch=2)
+    scfg = _capi.StreamConfig()
+    assert L.siftmi_stream_default_config(C.byref(scfg), 2) == 0 and (scfg.steps_in_flight, scfg.result_sets) == (2, 0)
+    h = C.c_void_p()
+    for field, bad in (("frames_per_step", 0), ("steps_in_flight", 5), ("result_sets", 65), ("format", 7), ("kp_per_frame", -1)):
+        c2 = _capi.StreamConfig.from_buffer_copy(scfg)
+        setattr(c2, field, bad)
+        assert L.siftmi_stream_create(eng.h, C.byref(c2), C.byref(h)) == _capi.E_BADARG, field
+    assert L.siftmi_stream_create(None, C.byref(scfg), C.byref(h)) == _capi.E_BADARG
+    fs = smstream.FrameStream(eng, 2, pipeline=2, result_sets=2)
+    r = _capi.StepHost()
+    assert L.siftmi_stream_result_host(fs.h, 0, C.byref(r)) == _capi.E_STATE          # nothing submitted yet
+    assert L.siftmi_stream_wait_upload(fs.h, 0) == _capi.E_BADARG
+    fa = np.stack([blob_frame(320, 240, i) for i in range(2)])
+    fb = np.stack([blob_frame(320, 240, 5 + i, n_blobs=80) for i in range(2)])
+    wa, wb = eng.detect_describe_batch(fa), eng.detect_describe_batch(fb)
+    pa, pb = sm.pinned_empty(fa.shape, np.uint8), sm.pinned_empty(fb.shape, np.uint8)
+    pa[...] = fa; pb[...] = fb
+    s0 = fs.run_host(pa)
+    fs.wait_upload(s0)
+    pa[...] = 0                                              # legal after wait_upload: the step still sees its own frames
+    s1 = fs.run_host(pb)
+    assert (s0, s1) == (0, 1)
+    v0 = fs.results_host(back=1, copy=False)
+    v1 = fs.results_host(back=0, copy=False)
+    assert v0["step"] == 0 and v0["keypoints"].tobytes() == wa[0].tobytes() and v0["descriptors"].tobytes() == wa[2].tobytes()
+    assert v1["step"] == 1 and v1["keypoints"].tobytes() == wb[0].tobytes() and v1["descriptors"].tobytes() == wb[2].tobytes()
+    assert L.siftmi_stream_result_host(fs.h, 2, C.byref(r)) == _capi.E_BADARG          # only 2 result sets / 2 steps so far
+    assert L.siftmi_stream_wait_consumed(fs.h, 1) == 0 and L.siftmi_stream_wait_consumed(fs.h, 2) == _capi.E_BADARG
+    # the views of step 0 stay valid while step 2 is NOT yet submitted; after two more submits its set has been reused
+    assert v0["keypoints"].tobytes() == wa[0].tobytes()
+    pa[...] = fa
+    fs.run_host(pa); fs.run_host(pb)
+    assert L.siftmi_stream_result_host(fs.h, 2, C.byref(r)) == _capi.E_BADARG
+    assert fs.results_host(back=1)["keypoints"].tobytes() == wa[0].tobytes()
+    # strided host frames: rows and frames padded
+    padded = sm.pinned_empty((2, 250, 336, 4), np.uint8)
+    padded[...] = 99
+    padded[:, :240, :320] = fb
+    step = C.c_int64()
+    _capi.check(L.siftmi_stream_submit_host(fs.h, padded.ctypes.data, padded.strides[1], padded.strides[0], C.byref(step)))
+    fs.step_no = step.value
+    assert fs.results_host()["descriptors"].tobytes() == wb[2].tobytes()
+    assert L.siftmi_stream_submit_host(fs.h, padded.ctypes.data, 16, padded.strides[0], C.byref(step)) == _capi.E_BADARG   # row stride < a row
+    fs.close()
+    # overflow through the host view + a gray float stream
+    small = sm.Engine(320, 240, n_octaves=3, max_batch=2, max_keypoints=8, max_descriptors=8)
+    fo = smstream.FrameStream(small, 2)
+    fo.run(smstream.DeviceFrames(fa))
+    with pytest.raises(sm.SiftmiError) as e:
+        fo.results_host()
+    assert e.value.code == _capi.E_CAPACITY and fo.results_host(allow_capacity=True)["overflow_flags"] & 2
+    fo.close(); small.close()
+    g = (fa[..., 1].astype(np.float32) / np.float32(255)).astype(np.float32)          # R = G = B frames: luma = the channel
+    wg = eng.detect_describe_batch(g)
+    ff = smstream.FrameStream(eng, 2, fmt=_capi.FMT_GRAYF32)
+    ff.run(smstream.DeviceFrames(g))
+    assert ff.results_host()["descriptors"].tobytes() == wg[2].tobytes()
+    ff.close()
+    for p_ in (pa, pb, padded):
+        sm.pinned_release(p_)
+    eng.close()
+
+
 def _run_c_host(tmp_path, mode, sets, steps, W=640, H=480, n_oct=3):
     import os
     import subprocess

@@ -3,18 +3,14 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import torch
-
 import siftmetal_amd as sm
 from siftmetal_amd import stream as smstream
 from tests.synth import blob_frame
 
-dev = torch.device("cuda", 0)
 eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=1)
-fs = smstream.FrameStream(eng, 1, device=dev)
-d = torch.from_numpy(blob_frame(1920, 1080, 0)[None]).to(dev)
+fs = smstream.FrameStream(eng, 1)
+d = smstream.DeviceFrames(blob_frame(1920, 1080, 0)[None])
 for _ in range(12):
     fs.run(d)
-torch.cuda.synchronize()
+    fs.synchronize()
 print(fs.results_host()["n_descriptors"])
