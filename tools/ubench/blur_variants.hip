@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include "dense_kernels.hip.h"
+#include "blur_ws.hip.h"
 using namespace siftmi;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -112,6 +113,13 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " +12KB LDS (one workgroup per CU fewer)", c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0>), grid, dim3(256), G::lds_bytes + 12288, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
     VRL(32, 256, 4)
+    // round 3 experiment: wave-specialised ring (blur_ws.hip.h), R >= 9 only
+    if constexpr (R >= 9) {
+#define VWS(CHR_) { const int tx = c.w / 128, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("ring WS (2 H waves + 2 V waves, S=16) rows/chunk=" #CHR_, c, R, [&] { hipLaunchKernelGGL((blur_ring_ws_kernel<R>), grid, dim3(256), 64 * 160 * 4, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_); }); }
+        VWS(256) VWS(128) VWS(512)
+    }
     // with the extrema activity flags (ACT) as layers 2 ... nspo+1 of the pipeline write them
 #define VRA(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
