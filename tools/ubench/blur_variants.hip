@@ -114,11 +114,22 @@ static void bench_R(Ctx &c, float rho) {
         run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " +12KB LDS (one workgroup per CU fewer)", c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0>), grid, dim3(256), G::lds_bytes + 12288, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
     VRL(32, 256, 4)
     // round 3 experiment: wave-specialised ring (blur_ws.hip.h), R >= 9 only
-    if constexpr (R >= 9) {
+    if constexpr (R >= 8) {
 #define VWS(CHR_) { const int tx = c.w / 128, nch = (c.h + CHR_ - 1) / CHR_; \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("ring WS (2 H waves + 2 V waves, S=16) rows/chunk=" #CHR_, c, R, [&] { hipLaunchKernelGGL((blur_ring_ws_kernel<R>), grid, dim3(256), 64 * 160 * 4, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_); }); }
+        run_variant("ring WS (2 H waves + 2 V waves, S=16) rows/chunk=" #CHR_, c, R, [&] { hipLaunchKernelGGL((blur_ring_wsx_kernel<R>), grid, dim3(256), 64 * 160 * 4, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_); }); }
         VWS(256) VWS(128) VWS(512)
+#define VWSM(CHR_, MAP_) { const int tx = c.w / 128, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("ring WS rolemap=" #MAP_ " rows/chunk=" #CHR_, c, R, [&] { hipLaunchKernelGGL((blur_ring_wsx_kernel<R, MAP_>), grid, dim3(256), 64 * 160 * 4, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_); }); }
+        VWSM(256, 1) VWSM(256, 2) VWSM(512, 1) VWSM(512, 2)
+        if constexpr (R >= 9) {     // the shipping wave-specialised kernel (dense_kernels.hip.h), without and with the activity flags
+#define VWSP(CHR_, ACT_) { using Gw = RingWsGeom<R>; const int tx = (c.w + 127) / 128, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        const int ncell = (c.w + 63) / 64; Activity act{(ACT_) ? (unsigned char *)c.diag : nullptr, (size_t)c.h * ncell, ncell, 0.8f * 0.0133f}; \
+        run_variant("ring WS shipping kernel ACT=" #ACT_ " rows/chunk=" #CHR_, c, R, [&] { hipLaunchKernelGGL((blur_ring_ws_kernel<R, ACT_>), grid, dim3(256), (ACT_) ? Gw::lds_bytes_act : Gw::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, act); }); }
+            VWSP(256, false) VWSP(256, true)
+        }
     }
     // with the extrema activity flags (ACT) as layers 2 ... nspo+1 of the pipeline write them
 #define VRA(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
