@@ -212,7 +212,11 @@ int siftmi_device_synchronize(int hip_device);
    k + result_sets is submitted.  Nothing here blocks the host except the *_host result call and the explicit waits.
 
    Stream arguments (`void *..._stream`) are hipStream_t handles: NULL is the device's legacy default stream,
-   SIFTMI_NO_STREAM means "no ordering wanted". */
+   SIFTMI_NO_STREAM means "no ordering wanted".
+   Like a context, a stream is not re-entrant: one host thread drives it.  The borrowed context must not be used for
+   other calls while steps are in flight (its scratch is the stream's), and must outlive the stream.  Defaults hold
+   32 768 keypoints + 49 152 descriptors per frame in each result set (64 frames: 0.5 GB per set) beside one pyramid
+   per context; every size is in siftmi_stream_config. */
 #define SIFTMI_NO_STREAM ((void *)(intptr_t)-1)
 
 typedef struct siftmi_stream siftmi_stream;
@@ -308,7 +312,9 @@ typedef struct siftmi_gathered {
     int32_t resolved, reserved;
 } siftmi_gathered;
 
-/* rank 0 creates the id and hands it to the other ranks out of band (a file, a socket, MPI, torch.distributed ...) */
+/* An exchange belongs to one stream: destroy it before the stream.  Its calls marked "collective" must be made by every
+   rank in the same order (they enqueue RCCL collectives).
+   rank 0 creates the id and hands it to the other ranks out of band (a file, a socket, MPI, torch.distributed ...) */
 int  siftmi_exchange_unique_id(void *id /* SIFTMI_UNIQUE_ID_BYTES */);
 /* collective over the `world` ranks: ncclCommInitRank on the stream's device */
 int  siftmi_exchange_create(siftmi_stream *s, const void *unique_id, int rank, int world, siftmi_exchange **out);

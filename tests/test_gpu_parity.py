@@ -253,29 +253,26 @@ def test_full_size_1080p_properties(sm):
 
 
 def test_device_resident_batch_graph_replay_matches_host_api(sm):
-    """siftmi_detect_describe_batch_device (torch-owned HBM buffers, hipGraph capture + replay on torch's
+    """siftmi_detect_describe_batch_device (frames and results in HBM, hipGraph capture + replay on the frame stream's launch
     stream) returns exactly what the host-facing batch API returns; replays are bit-identical."""
-    import torch
     from siftmetal_amd import stream as smstream
     frames = np.stack([blob_frame(320, 240, i) for i in range(5)])
     eng = sm.Engine(320, 240, n_octaves=3, max_batch=2)
     want = eng.detect_describe_batch(frames)
-    dev = torch.device("cuda", 0)
-    d_frames = torch.from_numpy(frames).to(dev)
-    fs = smstream.FrameStream(eng, 5, device=dev)
+    d_frames = smstream.DeviceFrames(frames)
+    fs = smstream.FrameStream(eng, 5)
     outs = []
     for _ in range(3):                       # capture, then two replays
         fs.run(d_frames)
-        torch.cuda.synchronize()
+        fs.synchronize()
         outs.append(fs.results_host())
     for r in outs:
         assert r["n_keypoints"] == len(want[0]) and r["n_descriptors"] == len(want[2])
         assert np.array_equal(r["keypoints"], want[0]) and np.array_equal(r["descriptors"], want[2])
         assert np.array_equal(r["counts"][0], want[1]) and np.array_equal(r["counts"][1], want[3])
     nog = sm.Engine(320, 240, n_octaves=3, max_batch=2, use_hip_graph=0)
-    fs2 = smstream.FrameStream(nog, 5, device=dev)
+    fs2 = smstream.FrameStream(nog, 5)
     fs2.run(d_frames)
-    torch.cuda.synchronize()
     r2 = fs2.results_host()
     assert np.array_equal(r2["keypoints"], want[0]) and np.array_equal(r2["descriptors"], want[2])
 
@@ -560,22 +557,40 @@ def test_approximate_match_through_reference_api(sm):
     assert len(got) > 20
 
 
-def test_frame_stream_is_ordered_with_torch_default_stream(sm):
-    """Regression: torch's default stream has a NULL handle, which the C ABI reads as "the context's own stream"; the
-    FrameStream must still order its kernels after the frame upload and before the result read-back, on the first call."""
-    import torch
-    from siftmetal_amd import stream as smstream
-    dev = torch.device("cuda", 0)
-    frame = blob_frame(640, 480, 3)
-    eng = sm.Engine(640, 480, n_octaves=3, max_batch=2)
-    _, kc, _, dc = eng.detect_describe_batch(np.stack([frame, frame]))
-    fs = smstream.FrameStream(eng, 2, device=dev)
-    assert torch.cuda.current_stream(dev).cuda_stream == 0
-    fs.run(torch.from_numpy(np.stack([frame, frame])).to(dev))          # temporary tensor, no explicit synchronisation
-    r = fs.results_host()
-    assert r["n_keypoints"] == int(kc.sum()) > 0 and r["n_descriptors"] == int(dc.sum()) > 0
-    np.testing.assert_array_equal(r["counts"][0], kc)
-    eng.close()
+def test_frame_stream_is_ordered_with_torch_default_stream():
+    """A caller that hands torch CUDA tensors to the binding: torch's default stream has a NULL handle (the legacy stream); the
+    stream's kernels must be ordered after the upload torch enqueued there and the frames kept alive although the caller drops
+    them at once.  Runs in its own interpreter with torch imported FIRST -- the order in which a process gets ONE HIP runtime
+    (PyTorch bundles its own; loading libsiftmi.so first and torch later would put two runtimes into the process)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        import numpy as np
+        import torch
+        sys.path.insert(0, %r)
+        import siftmetal_amd as sm
+        from siftmetal_amd import stream as smstream
+        from tests.synth import blob_frame
+        dev = torch.device("cuda", 0)
+        frame = blob_frame(640, 480, 3)
+        eng = sm.Engine(640, 480, n_octaves=3, max_batch=2)
+        _, kc, _, dc = eng.detect_describe_batch(np.stack([frame, frame]))
+        fs = smstream.FrameStream(eng, 2, device=dev)
+        assert torch.cuda.current_stream(dev).cuda_stream == 0
+        for _ in range(3):
+            fs.run(torch.from_numpy(np.stack([frame, frame])).to(dev))          # temporary tensor, no explicit synchronisation
+            r = fs.results_host()
+            assert r["n_keypoints"] == int(kc.sum()) > 0 and r["n_descriptors"] == int(dc.sum()) > 0
+            assert np.array_equal(r["counts"][0], kc)
+        fs.close(); eng.close()
+        print("ok")
+    """ % root)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and b"ok" in p.stdout, p.stderr.decode()[-2000:]
 
 
 @pytest.mark.parametrize("frames,lockstep", [(4, 4), (6, 4), (2, 2)])
@@ -583,18 +598,16 @@ def test_graph_replays_stay_correct(sm, frames, lockstep):
     """Regression: hipMemsetAsync nodes captured into the hipGraph stopped clearing the counters from the third launch on
     (ROCm 7.2, non-forked graphs), so later replays accumulated garbage.  Counters are now cleared by a kernel; every
     replay, synchronised and read back, must reproduce the host API's counts."""
-    import torch
     from siftmetal_amd import stream as smstream
-    dev = torch.device("cuda", 0)
     w, h = 1280, 960                                    # 4 frames x 2560 x 1920 > 16 Mpx: the serial (non-forked) graph
     batch = np.stack([blob_frame(w, h, i) for i in range(frames)])
     eng = sm.Engine(w, h, n_octaves=4, max_batch=lockstep)
     _, kc, _, dc = eng.detect_describe_batch(batch)
-    fs = smstream.FrameStream(eng, frames, device=dev)
-    d = torch.from_numpy(batch).to(dev)
+    fs = smstream.FrameStream(eng, frames)
+    d = smstream.DeviceFrames(batch)
     for launch in range(6):
         fs.run(d)
-        torch.cuda.synchronize()
+        fs.synchronize()
         r = fs.results_host()
         assert (r["n_keypoints"], r["n_descriptors"]) == (int(kc.sum()), int(dc.sum())), "launch %d" % launch
         np.testing.assert_array_equal(r["counts"][0], kc)
@@ -618,9 +631,7 @@ def test_config2_64x1080p_lockstep_graph_replays_equal_lockstep1(sm, lockstep):
     with activity flags on octaves 0 and 1, flagged-row extrema scan), direct launches on the first call, capture on the
     second, then two replays: every frame's records of every run are bit-equal to what a lock-step-1 engine (tile /
     small-launch paths, full extrema scan) returns for that frame."""
-    import torch
     from siftmetal_amd import stream as smstream
-    dev = torch.device("cuda", 0)
     W, H, F = 1920, 1080, 64
     base = [blob_frame(W, H, i) for i in range(8)]
     one = sm.Engine(W, H, n_octaves=4, max_batch=1)
@@ -628,11 +639,11 @@ def test_config2_64x1080p_lockstep_graph_replays_equal_lockstep1(sm, lockstep):
     one.close()
     frames = np.stack([base[i % 8] for i in range(F)])
     eng = sm.Engine(W, H, n_octaves=4, max_batch=lockstep)
-    fs = smstream.FrameStream(eng, F, device=dev)
-    d = torch.from_numpy(frames).to(dev)
+    fs = smstream.FrameStream(eng, F)
+    d = smstream.DeviceFrames(frames)
     for run in range(4):
         fs.run(d)
-        torch.cuda.synchronize()
+        fs.synchronize()
         r = fs.results_host()
         assert r["overflow_flags"] == 0
         for f in range(F):
@@ -674,25 +685,24 @@ def test_dog_readback_matches_oracle(sm, butterfly_bgra):
 def test_device_path_reports_overflow_and_orders_following_calls(sm):
     """the device-resident call must surface list overflow (d_totals[2]) instead of truncating silently, and a
     following call on the context's own stream must be ordered after it (shared scratch)."""
-    import torch
     from siftmetal_amd import _capi, stream as smstream
-    dev = torch.device("cuda", 0)
     frames = np.stack([blob_frame(640, 480, i) for i in range(3)])
     small = sm.Engine(640, 480, n_octaves=3, max_batch=2, max_keypoints=16, max_descriptors=16)
-    fs = smstream.FrameStream(small, 3, device=dev)
-    fs.run(torch.from_numpy(frames).to(dev))
+    fs = smstream.FrameStream(small, 3)
+    fs.run(smstream.DeviceFrames(frames))
     with pytest.raises(sm.SiftmiError) as e:
         fs.results_host()
     assert e.value.code == _capi.E_CAPACITY
     r = fs.results_host(allow_capacity=True)
     assert r["overflow_flags"] & 2 and r["counts"].max() <= 16
+    fs.close()
     small.close()
     # ordering: device call on a side stream, then introspection + a host-facing call on the context's stream, no explicit sync
     eng = sm.Engine(640, 480, n_octaves=3, max_batch=3)
     want = eng.detect_describe_batch(frames)
     g_want = eng.gaussian(1, 3, frame=2)
-    fs = smstream.FrameStream(eng, 3, device=dev)
-    d = torch.from_numpy(frames).to(dev)
+    fs = smstream.FrameStream(eng, 3)
+    d = smstream.DeviceFrames(frames)
     for _ in range(3):
         fs.run(d)
         assert np.array_equal(eng.gaussian(1, 3, frame=2), g_want)          # waits for the device call
@@ -704,18 +714,16 @@ def test_device_path_reports_overflow_and_orders_following_calls(sm):
 
 
 def test_frame_stream_two_steps_in_flight_equal_one_at_a_time(sm):
-    """FrameStream(pipeline=2): consecutive steps alternate between two contexts on two streams and nothing joins them with
-    torch's current stream, so step k+1 is launched before step k's results are read.  Every step's packed results must be
+    """FrameStream(pipeline=2) = siftmi_stream with two steps in flight: consecutive steps alternate between two contexts on two
+    launch streams, so step k+1 is launched before step k's results are read.  Every step's packed results must be
     byte-identical to the host API's for that step's frames (three frame sets: each context sees its inputs change)."""
-    import torch
     from siftmetal_amd import stream as smstream
-    dev = torch.device("cuda", 0)
     sets = [np.stack([blob_frame(640, 480, 20 * j + i, n_blobs=150 + 100 * j) for i in range(4)]) for j in range(3)]
     eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
     want = [eng.detect_describe_batch(f) for f in sets]
-    fs = smstream.FrameStream(eng, 4, device=dev, pipeline=2)
+    fs = smstream.FrameStream(eng, 4, pipeline=2)
     assert len(fs.engines) == 2 and fs.engines[1].h.value != eng.h.value
-    dsets = [torch.from_numpy(f).to(dev) for f in sets]
+    dsets = [smstream.DeviceFrames(f) for f in sets]
 
     def check(r, j, step):
         k, kc, d, dc = want[j]
@@ -729,8 +737,8 @@ def test_frame_stream_two_steps_in_flight_equal_one_at_a_time(sm):
         if step >= 1:
             check(fs.results_host(previous=True), (step - 1) % 3, step - 1)     # read step k-1 while step k runs
     check(fs.results_host(), (n - 1) % 3, n - 1)
-    for e in fs.engines:
-        e.close()
+    fs.close()
+    eng.close()
 
 
 @pytest.mark.parametrize("pipeline", [1, 2])
@@ -738,14 +746,16 @@ def test_frame_stream_host_fed_steps_equal_host_api(sm, pipeline):
     """FrameStream.run_host: frames in page-locked host memory, uploaded on a copy stream into alternating staging buffers
     (the upload of step k+1 may run while step k computes).  The host tensor is rewritten between steps as soon as the step
     that uploaded it has been launched and its predecessor read -- every step must still see its own frames."""
-    import torch
     from siftmetal_amd import stream as smstream
-    dev = torch.device("cuda", 0)
     sets = [np.stack([blob_frame(640, 480, 30 * j + i, n_blobs=120 + 90 * j) for i in range(4)]) for j in range(3)]
     eng = sm.Engine(640, 480, n_octaves=3, max_batch=4)
     want = [eng.detect_describe_batch(f) for f in sets]
-    fs = smstream.FrameStream(eng, 4, device=dev, pipeline=pipeline)
-    pins = [torch.from_numpy(f).pin_memory() for f in sets]
+    fs = smstream.FrameStream(eng, 4, pipeline=pipeline)
+    pins = []
+    for f in sets:
+        pin = sm.pinned_empty(f.shape, np.uint8)
+        pin[...] = f
+        pins.append(pin)
     n = 8
     for step in range(n):
         fs.run_host(pins[step % 3])
@@ -760,8 +770,10 @@ def test_frame_stream_host_fed_steps_equal_host_api(sm, pipeline):
     r = fs.results_host()
     k, kc, d, dc = want[(n - 1) % 3]
     assert r["keypoints"].tobytes() == k.tobytes() and r["descriptors"].tobytes() == d.tobytes()
-    for e in fs.engines:
-        e.close()
+    fs.close()
+    eng.close()
+    for pin in pins:
+        sm.pinned_release(pin)
 
 
 @pytest.mark.parametrize("pipeline", [1, 2])
