@@ -476,11 +476,8 @@ def main():
         d_dense.close()
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(frames_np)
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # everything that can still write to fd 1 (RCCL prints its version banner when the communicator goes) is torn down BEFORE
+    # stdout is restored: the contract is ONE JSON line
     if world > 1:
         dist.barrier()                                      # rank 0's extra measurements are done: all ranks leave together (the exchange is collective)
     if plain is not runner:
@@ -489,6 +486,12 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                                           # and whatever library teardown prints at exit goes to stderr
 
 
 if __name__ == "__main__":

@@ -30,7 +30,8 @@ def _split(arr, counts):
 
 CASES = [
     ("butterfly", None, 7, 3),              # the reference's own test image, its default 7 octaves
-    ("blob640", (640, 480), 3, 3),          # BASELINE configs[0]
+    ("blob640", (640, 480), 3, 3),          # BASELINE configs[0] (BGRA8, the reference's texture format)
+    ("gray640", (640, 480), 3, 3),          # BASELINE configs[0] as worded: a 640x480 GRAYSCALE frame (gray-8 input, no luma step)
     ("odd", (157, 93), 3, 3),               # widths not multiples of 4 -> scalar load/store path
     ("tiny", (40, 36), 2, 3),
     ("nspo4", (256, 192), 3, 4),            # other scales-per-octave: different tap counts / layer counts
@@ -45,6 +46,8 @@ def _image(name, size, butterfly_bgra):
         return butterfly_bgra
     if name == "odd":
         return blob_frame(size[0], size[1], 7, n_blobs=60, gray=True)
+    if name == "gray640":
+        return blob_frame(size[0], size[1], 2, gray=True)
     return blob_frame(size[0], size[1], 1)
 
 
@@ -1052,3 +1055,23 @@ def test_bench_line_contract():
     shapes = r["by_launch_shape"]
     assert len(shapes) == 20 and shapes["o0_l5"]["kernel"].startswith("blur_ring_kernel<13") and shapes["o0_l3"]["decimating"]
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_line_with_the_exchange_on_one_rank():
+    """SIFTMI_FORCE_GATHER=1: the N > 1 path of bench.py (unique id, siftmi_exchange_create / _gather on every step on the side
+    stream, _finish, the exchange fields of the line) with the one rank a 1-GPU box has."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIFTMI_FORCE_GATHER="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras", "--no-roofline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    c = json.loads(lines[0])["config"]
+    assert c["rccl_ranks"] == 1 and c["all_gather_ms_per_step"] > 0 and c["all_gather_bytes_received_per_rank_per_step"] > 10 ** 6
+    assert c["all_gather_steps_overflowed"] == 0 and c["all_gather_steps_regathered"] == 0
+    assert c["ms_per_step_by_rank"]["min"] == c["ms_per_step_by_rank"]["max"] > 0
