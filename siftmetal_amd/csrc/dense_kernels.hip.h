@@ -155,6 +155,8 @@ struct VTaps {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) volatile f32x2 lds_cv_f32x2;
+typedef __attribute__((address_space(3))) volatile float lds_cv_f32;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Mirror extension without a branch (both blur kernels' row loads).  For w % 4 == 0 a float4 at columns gx ... gx+3
 // (gx % 4 == 0) lies wholly inside or wholly outside the image, and outside it is the float4 at -gx - 4 (left) or
@@ -484,7 +486,7 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 // the FMA issue rate three waves per SIMD reach (tools/ubench/ubench_valu: 3.4 / 2.9 / 2.7 cycles per v_fma_f32 at 2 / 4 / 8
 // waves), not at LDS latency.  On for R <= 8.
 template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12),
-          bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */>
+          bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */, bool VM = false>
 __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                              int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
@@ -629,6 +631,14 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         stage_rows(-2 * R, S);
     }
     const VTapsSym<R> tw(wt);
+    // VM: column k of the banded tap matrix, row i of a 16-row tile = wtab[k - i + 15] (zero outside the band)
+    float *wtab = lds + LW * NR + NR * G::NSUB;
+    if (VM) {
+        float wq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < G::NT; i++) wq = (tid - 15 == i) ? wt.w[i] : wq;
+        if (tid < G::NT + 30) wtab[tid] = wq;
+    }
 
     unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
     auto stamp = [&](int k) {                                // DBG & 1: time since the previous stamp -> dsum[k]
@@ -760,6 +770,47 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         lds_barrier();                                       // B2: blurred rows complete
         stamp(2);
 
+        if constexpr (VM) {
+            // vertical pass on the matrix cores: out(16 rows x 64 columns) = T(16 x K) B(K x 64), K = 16 + 2R window rows, T the banded
+            // tap matrix; one v_mfma_f32_16x16x1 (4 blocks of 16 columns) per window row, i.e. per output a k-ordered fmaf chain over
+            // its 2R + 1 taps with exact zeros before and after -- bit-identical to the vector form.  Wavefront wv owns rows
+            // (wv >> 1) 16 ..., columns (wv & 1) 64 ...; lane (b = lane / 16, n = lane % 16) feeds column 4 n + b of block b, so
+            // that after the chain it holds columns 4 n ... 4 n + 3 of rows 4 (lane / 16) + v: one b128 store per row.
+            static_assert(S == 32 && !ACT && !DEC, "VM: 2 x 2 tiles of 16 x 64 per step");
+            const int tr = (wv >> 1) * 16, tc = (wv & 1) * 64;
+            const int u0 = st * S + tr - 2 * R;              // even
+            const int n = lane & 15, g = lane >> 4;
+            const int col = RP + tc + 4 * n + g;
+            const float *colp = lds + col, *colx = lds + (col ^ (H8 ? 4 : 0));
+            const float *wrow = wtab + 15 - n;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < ((DBG & 16) ? 0 : 16 + 2 * R); k++) {
+                const int slot = (u0 + k + NR) & (NR - 1);
+                const float bv = *(const lds_cv_f32 *)(((k & 1) ? colx : colp) + slot * LW);
+                const float av = *(const lds_cv_f32 *)(wrow + k);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(av, bv, acc, 0, 0, 0);
+            }
+            stamp(3);
+            const int gx = x0 + tc + 4 * n;
+#pragma unroll
+            for (int v = 0; v < ((DBG & 2) ? 0 : 4); v++) {
+                const int gy = y0 + tr + 4 * g + v;
+                if (!FULL && gy >= h) continue;
+                float *o = out + (size_t)gy * w + gx;
+                const f32x4 q = {acc[v], acc[4 + v], acc[8 + v], acc[12 + v]};
+                if (FULL || (gx + 3 < w && (w & 3) == 0)) {
+                    *reinterpret_cast<f32x4 *>(o) = q;
+                } else {
+                    if (gx + 0 < w) o[0] = q.x;
+                    if (gx + 1 < w) o[1] = q.y;
+                    if (gx + 2 < w) o[2] = q.z;
+                    if (gx + 3 < w) o[3] = q.w;
+                }
+            }
+        } else
         // vertical pass: wavefront wv owns output rows wv RB ... wv RB + RB - 1 of the step, a lane 2 columns
         {
             const int u0 = st * S + wv * RB - 2 * R;         // first window row (wave-uniform)

@@ -1,0 +1,26 @@
+"""Stage times of one 64 x 1080p step on dense natural texture (bench.py's config.dense), per-launch hipEvents.
+usage: [SIFTMI_LIB=<experiment build>] python tools/dense_stage_times.py [steps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import siftmetal_amd as sm
+from siftmetal_amd import stream as smstream
+import bench
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+F = 64
+eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=F)
+fs = smstream.FrameStream(eng, F)
+d = smstream.DeviceFrames(bench.make_dense_frames(F))
+for _ in range(2):
+    fs.run(d)
+fs.synchronize()
+eng.enable_timings(True)
+eng.reset_timings()
+for _ in range(steps):
+    fs.run(d)
+fs.synchronize()
+tm = eng.timings()
+r = fs.results_host()
+print(os.environ.get("SIFTMI_LIB", "libsiftmi.so"), {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0}, r["n_keypoints"], r["n_descriptors"], flush=True)

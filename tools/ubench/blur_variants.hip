@@ -107,6 +107,12 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_ " HPIPE", c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, H8_, true>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
     VRP(32, 256, 3, true) VRP(32, 256, 2, true)
+    // round 3: the vertical pass on the matrix cores (VM): one v_mfma_f32_16x16x1 per window row against the banded tap matrix
+#define VRM(S_, CHR_, MINW_, H8_, HP_) { using G = RingGeom<R, S_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("ring VM (MFMA vertical pass) rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_ " HPIPE=" #HP_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, H8_, HP_, true>), grid, dim3(256), G::lds_bytes_act + 256, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
+    VRM(32, 256, 4, (R <= 12), false) VRM(32, 256, 3, true, false) VRM(32, 256, 3, true, true) VRM(32, 128, 4, (R <= 12), false)
     // occupancy sensitivity: the same kernel with 12 KB of unused dynamic LDS (3 instead of 4 workgroups per CU at R <= 8, 2 instead of 3 above)
 #define VRL(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
