@@ -79,13 +79,18 @@ typedef struct siftmi_config {
     int32_t use_hip_graph;              /* 1 (default) = siftmi_detect_describe_batch_device captures its
                                            launch sequence into a hipGraph and replays it while the
                                            caller keeps passing the same buffers                    */
-    int32_t count_raw_extrema;          /* 0 (default): on large launches the extrema scan skips image rows that the blur
-                                           kernels flagged as unable to hold a candidate (no |DoG| above 0.8 x
+    int32_t count_raw_extrema;          /* 0 (default): on octaves of >= 1.5 Mpixel per launch the extrema scan skips image rows
+                                           that the blur kernels flagged as unable to hold a candidate (no |DoG| above 0.8 x
                                            dog_threshold); same candidates, keypoints and descriptors, but the raw_extrema
-                                           statistic then counts tested rows only.  1 = scan every row, exact raw_extrema. */
+                                           statistic then counts tested rows only (siftmi_stats.raw_extrema_exact = 0).
+                                           1 = scan every row, exact raw_extrema. */
     int32_t blur_march_min_blocks;      /* launches with at least this many 128 x 128 workgroups use the marching blur
                                            (default 2000; 1 = always, for tests) */
-    int32_t reserved[4];
+    int32_t blur_chain_max_tiles;       /* an octave of at most this many 64 x 64 tiles (frames x tiles) gets its Gaussian layers 1-3 and
+                                           4-5 from ONE launch each (single frames: fewer dependent launches per call).  0 = default
+                                           (256: the 960x540 and 480x270 octaves of one 1920x1080 frame), -1 = off.  Default schedule only (nspo = 3,
+                                           taps 11 ... 27), octave width a multiple of 4, at least 64 x 64 */
+    int32_t reserved[3];
 } siftmi_config;
 
 /* Replaces SIFTExtremaResult (Sources/MetalShaders/include/SIFTExtrema.h:14-18). */

@@ -196,6 +196,8 @@ struct Blur2Geom {
     static_assert((REM == 0 || REM == 2) && (NPF4 * 4 + REM) * 8 == LW, "row decomposition");
     static constexpr int V_ITEMS = (TW / 4) * (TH / RB);
     static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
+    static constexpr int NSUB = TW / 8;                                       // activity flags: max|Eh| per (window row, 8-column sub-cell) behind the tile
+    static constexpr size_t lds_bytes_act = lds_bytes + (size_t)LH * NSUB * sizeof(float);
     // seed variant: luma of the input pixels under the staged 2x window, computed once per workgroup
     static constexpr int LWI = LW / 2 + 3, LHI = LH / 2 + 3;
     static constexpr size_t seed_lds_bytes = lds_bytes + (size_t)LWI * LHI * sizeof(float);
@@ -203,12 +205,16 @@ struct Blur2Geom {
     static_assert(TH % RB == 0, "TH must be a multiple of RB");
 };
 
-template <int R, int TH_, int NTHR_, int HO_, int RB_, bool SEED, int MINW = 1, int KCH = 0, bool XCD = false, bool DEC = false>
+// ACT (round 3): the DoG activity flags of the marching kernel (see Activity) from the tile kernel, so that a single large
+// frame's extrema scan can skip rows too: max|Eh| per (window row, 8-column sub-cell) = two lanes of the horizontal pass,
+// |Ev| from the vertical pass's centre operand, one ballot per output row.
+template <int R, int TH_, int NTHR_, int HO_, int RB_, bool SEED, int MINW = 1, int KCH = 0, bool XCD = false, bool DEC = false, bool ACT = false>
 __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                            size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt, SeedSource seed, int n_frames,
-                                                           Decimate dec) {
+                                                           Decimate dec, Activity act) {
     using G = Blur2Geom<R, TH_, NTHR_, HO_, RB_>;
     constexpr int NTHR = G::NTHR;
+    static_assert(!ACT || (!SEED && G::V_ITEMS == NTHR && NTHR % 64 == 0 && (G::LH * (G::TW / 4)) % 64 == 0), "ACT: whole wavefronts in both passes");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     int bx = blockIdx.x, by = blockIdx.y, frame = blockIdx.z;
@@ -358,6 +364,13 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
             for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(G::RP - R - 4 * M0) + k + i], acc[k]);
         }
         *reinterpret_cast<float4 *>(rowp + G::RP + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (ACT) {                                               // |Eh| = |hb - input| at the lane's 4 pixels; the neighbour lane completes the sub-cell
+            float e = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) e = fmaxf(e, fabsf(acc[k] - v[(G::RP - R - 4 * M0) + k + R]));
+            e = fmaxf(e, __shfl_xor(e, 1));
+            if ((tid & 1) == 0) lds[G::LW * G::LH + row * G::NSUB + (c4 >> 3)] = e;
+        }
     }
     __syncthreads();
 
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
         const int cg = item & 31, rg = item >> 5;
         const float *colp = lds + (rg * G::RB) * G::LW + G::RP + cg * 4;
         float4 acc[G::RB];
+        float4 cen[ACT ? G::RB : 1];                             // hb under each output (the centre tap's operand)
 #pragma unroll
         for (int rr = 0; rr < G::RB; rr++) acc[rr] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
@@ -375,6 +389,7 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
 #pragma unroll
             for (int rr = 0; rr < G::RB; rr++) {
                 const int i = k - rr;
+                if (ACT && i == R) cen[rr] = v;
                 if (i >= 0 && i < G::NT) {
                     acc[rr].x = fmaf(tw.w[i], v.x, acc[rr].x);
                     acc[rr].y = fmaf(tw.w[i], v.y, acc[rr].y);
@@ -405,6 +420,19 @@ __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restr
                 float *o2 = dec.dst + (size_t)frame * dec.frame_stride + (size_t)(gy >> 1) * dec.w2 + (gx >> 1);
                 if ((gx >> 1) + 0 < dec.w2 && gx + 0 < w) o2[0] = acc[rr].x;
                 if ((gx >> 1) + 1 < dec.w2 && gx + 2 < w) o2[1] = acc[rr].z;
+            }
+        }
+        if (ACT) {                                               // 16 lanes = 64 columns = one cell of a row; a wavefront holds 2 row groups x 2 cells
+            const float lim = act.thr * 0.9999f;
+#pragma unroll
+            for (int rr = 0; rr < G::RB; rr++) {
+                const float eh = lds[G::LW * G::LH + (rg * G::RB + rr + R) * G::NSUB + (cg >> 1)];
+                const bool f = (gx + 0 < w && fabsf(acc[rr].x - cen[rr].x) + eh > lim) || (gx + 1 < w && fabsf(acc[rr].y - cen[rr].y) + eh > lim) ||
+                               (gx + 2 < w && fabsf(acc[rr].z - cen[rr].z) + eh > lim) || (gx + 3 < w && fabsf(acc[rr].w - cen[rr].w) + eh > lim);
+                const unsigned long long b = __ballot(f);
+                const int gy = y0 + rg * G::RB + rr, cell = (x0 >> 6) + (cg >> 4);
+                if ((tid & 15) == 0 && gy < h && cell < act.ncell)
+                    act.dst[(size_t)frame * act.frame_stride + (size_t)gy * act.ncell + cell] = (unsigned char)(((b >> (tid & 48)) & 0xffffull) != 0ull);
             }
         }
     }
@@ -486,7 +514,7 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 // the FMA issue rate three waves per SIMD reach (tools/ubench/ubench_valu: 3.4 / 2.9 / 2.7 cycles per v_fma_f32 at 2 / 4 / 8
 // waves), not at LDS latency.  On for R <= 8.
 template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12),
-          bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */, bool VM = false>
+          bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */, int VM = 0>
 __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                              int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
@@ -631,13 +659,17 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         stage_rows(-2 * R, S);
     }
     const VTapsSym<R> tw(wt);
-    // VM: column k of the banded tap matrix, row i of a 16-row tile = wtab[k - i + 15] (zero outside the band)
-    float *wtab = lds + LW * NR + NR * G::NSUB;
+    // VM: column k of the banded tap matrix, row i = lane % TM of a TM-row tile: tap k - i, zero outside the band
+    constexpr int TM = VM == 2 ? 16 : 4;
+    float va[VM ? TM + 2 * R : 1];
     if (VM) {
-        float wq = 0.0f;
 #pragma unroll
-        for (int i = 0; i < G::NT; i++) wq = (tid - 15 == i) ? wt.w[i] : wq;
-        if (tid < G::NT + 30) wtab[tid] = wq;
+        for (int k = 0; k < TM + 2 * R; k++) {
+            float wq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; i++) { const int t = k - i; if (t >= 0 && t < G::NT) wq = ((lane & (TM - 1)) == i) ? wt.w[t] : wq; }
+            va[k] = wq;
+        }
     }
 
     unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
@@ -770,29 +802,29 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
         lds_barrier();                                       // B2: blurred rows complete
         stamp(2);
 
-        if constexpr (VM) {
-            // vertical pass on the matrix cores: out(16 rows x 64 columns) = T(16 x K) B(K x 64), K = 16 + 2R window rows, T the banded
-            // tap matrix; one v_mfma_f32_16x16x1 (4 blocks of 16 columns) per window row, i.e. per output a k-ordered fmaf chain over
-            // its 2R + 1 taps with exact zeros before and after -- bit-identical to the vector form.  Wavefront wv owns rows
-            // (wv >> 1) 16 ..., columns (wv & 1) 64 ...; lane (b = lane / 16, n = lane % 16) feeds column 4 n + b of block b, so
-            // that after the chain it holds columns 4 n ... 4 n + 3 of rows 4 (lane / 16) + v: one b128 store per row.
+        if constexpr (VM == 2) {
+            // vertical pass on the matrix cores, 16 x 64 tile of wavefront wv = T(16 x K) B(K x 64), K = 16 + 2R window rows: one
+            // v_mfma_f32_16x16x1 (4 blocks of 16 columns, 32 cycles of the matrix pipe but 8 of the SIMD's issue) per window row.
+            // Lane (b = lane / 16, n = lane % 16) feeds column 4 n + b of block b and ends up with columns 4 n ... 4 n + 3 of rows
+            // 4 (lane / 16) + v: one b128 store per row.
             static_assert(S == 32 && !ACT && !DEC, "VM: 2 x 2 tiles of 16 x 64 per step");
             const int tr = (wv >> 1) * 16, tc = (wv & 1) * 64;
             const int u0 = st * S + tr - 2 * R;              // even
             const int n = lane & 15, g = lane >> 4;
             const int col = RP + tc + 4 * n + g;
             const float *colp = lds + col, *colx = lds + (col ^ (H8 ? 4 : 0));
-            const float *wrow = wtab + 15 - n;
+            float bv[16 + 2 * R];
+#pragma unroll
+            for (int r = 0; r < 16 + 2 * R; r++) {
+                const int slot = (u0 + r + NR) & (NR - 1);
+                bv[r] = *(const lds_cv_f32 *)(((r & 1) ? colx : colp) + slot * LW);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < ((DBG & 16) ? 0 : 16 + 2 * R); k++) {
-                const int slot = (u0 + k + NR) & (NR - 1);
-                const float bv = *(const lds_cv_f32 *)(((k & 1) ? colx : colp) + slot * LW);
-                const float av = *(const lds_cv_f32 *)(wrow + k);
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(av, bv, acc, 0, 0, 0);
-            }
+            for (int r = 0; r < ((DBG & 16) ? 0 : 16 + 2 * R); r++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(va[r], bv[r], acc, 0, 0, 0);
             stamp(3);
             const int gx = x0 + tc + 4 * n;
 #pragma unroll
@@ -808,6 +840,46 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                     if (gx + 1 < w) o[1] = q.y;
                     if (gx + 2 < w) o[2] = q.z;
                     if (gx + 3 < w) o[3] = q.w;
+                }
+            }
+        } else
+        if constexpr (VM == 1) {
+            // vertical pass on the matrix cores: a 4-row x 64-column tile is T(4 x K) B(K x 64) with K = 4 + 2R window rows and T the
+            // banded tap matrix, one v_mfma_f32_4x4x1 (16 blocks of 4 columns) per window row -- per output a k-ordered fmaf chain
+            // over its 2R + 1 taps with exact zeros before and after: bit-identical to the vector form.  Wavefront wv owns rows
+            // (wv >> 1) 16 ..., columns (wv & 1) 64 ... as four such tiles (four independent accumulator chains, a window row
+            // feeds up to four of them); lane l feeds column l and ends up with column l of the 16 rows.
+            static_assert(S == 32 && !ACT && !DEC, "VM: 2 x 2 tiles of 16 x 64 per step");
+            const int tr = (wv >> 1) * 16, tc = (wv & 1) * 64;
+            const int u0 = st * S + tr - 2 * R;              // even
+            const int col = RP + tc + lane;
+            const float *colp = lds + col, *colx = lds + (col ^ (H8 ? 4 : 0));
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            float bv[16 + 2 * R];                            // the whole window first: one LDS latency, not one per row
+#pragma unroll
+            for (int r = 0; r < 16 + 2 * R; r++) {
+                const int slot = (u0 + r + NR) & (NR - 1);
+                bv[r] = *(const lds_cv_f32 *)(((r & 1) ? colx : colp) + slot * LW);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < ((DBG & 16) ? 0 : 16 + 2 * R); r++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = r - 4 * q;
+                    if (k >= 0 && k < 4 + 2 * R) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(va[k], bv[r], acc[q], 0, 0, 0);
+                }
+            }
+            stamp(3);
+            const int gx = x0 + tc + lane;
+            if (FULL || gx < w) {
+#pragma unroll
+                for (int j = 0; j < ((DBG & 2) ? 0 : 16); j++) {
+                    const int gy = y0 + tr + j;              // wave-uniform
+                    if (!FULL && gy >= h) continue;
+                    out[(size_t)gy * w + gx] = acc[j >> 2][j & 3];
                 }
             }
         } else
@@ -916,6 +988,193 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
 #pragma unroll
         for (int k = 0; k < 8; k++) d[k] = dsum[k];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Up to three consecutive Gaussian layers of an octave in one launch (a frame or two per call).  As one launch per layer, every
+// layer of a single 1920x1080 frame is a 5-30 us kernel that re-stages its input, plus a dependency gap, on the call's critical
+// path (seed -> three layers each of octaves 0, 1, 2 -> octave 3's whole chain).  Here a workgroup keeps a T x T tile with a
+// halo of HALO = RA + RB + RC pixels in LDS and runs the cascaded blurs on it in place, the valid margin shrinking by R per
+// layer: 1.6 x (T = 64) to 2.4 x (T = 32) the arithmetic of the per-layer launches, one staging and one launch instead of three.
+// Same arithmetic as blur2_kernel -- horizontal pass, then vertical pass, k-ordered fmaf chains -- so the layers are
+// bit-identical.  Mirror extension (Common.hpp:15-22): every layer blurs the symmetric extension of the layer before it, and a
+// reflected position's own blur would sum its taps in reverse order (other roundings), so after each layer the cells of the
+// region outside the image are overwritten with the values at their mirrored positions (which the tile holds: HALO < T).
+// Needs w % 4 == 0 and w, h >= 64 (one reflection reaches every input).
+struct ChainWeights { TapWeights l[3]; };
+
+template <int T_, int NTHR_, int RA, int RB, int RC>
+struct ChainGeom {
+    static constexpr int T = T_, NTHR = NTHR_;
+    static constexpr int HALO = RA + RB + RC;
+    static constexpr int HP = (HALO + 3) & ~3;                  // staged halo: whole float4s
+    static constexpr int RW = T + 2 * HP;                       // region (rows and columns)
+    static constexpr int PADC = 16;                             // columns either side that the horizontal pass may read (never uses)
+    static constexpr int LW = RW + 2 * PADC, LH = RW + 4;       // + 4 rows the last vertical row group may read
+    static constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float);
+    static_assert(T % 4 == 0 && HALO < T && RA > 0, "the mirrored source of every halo cell lies in the tile");
+    static_assert(RA <= 16 && RB <= 16 && RC <= 16, "PADC");
+};
+
+// one layer, in place on the region in LDS.  MP = margin (cells beyond the tile, every side) on which the input layer is valid.
+template <typename G, int R, int MP, bool LAST>
+__device__ __forceinline__ void chain_layer(float *lds, const TapWeights &wt, float *__restrict__ out, int w, int h, int x0, int y0,
+                                            bool border, bool do_dec, float *__restrict__ dec_out, int w2, int h2) {
+    constexpr int MC = MP - R, NT = 2 * R + 1;
+    static_assert(MC >= 0, "halo");
+    const int tid = threadIdx.x;
+    const VTaps<NT> tw(wt);
+    // horizontal pass, in place: the rows on which the input is valid; 4 adjacent outputs per lane, a row's lanes in one wavefront
+    constexpr int HR0 = G::HP - MP, HR1 = G::HP + G::T + MP;
+    constexpr int G0 = (G::HP - MC) / 4, G1 = (G::HP + G::T + MC + 3) / 4;       // float4 column groups [G0, G1)
+    constexpr int LPR = (G1 - G0) <= 16 ? 16 : 32, LSH = LPR == 16 ? 4 : 5;      // lanes per row
+    static_assert(G1 - G0 <= 32 && HR0 >= 0 && HR1 <= G::RW, "a row's items fit half a wavefront");
+    constexpr int ML = -((R + 3) / 4), MH = (R + 3) / 4;                          // float4s around the lane's own: ML ... MH
+    for (int it = tid; it < (HR1 - HR0) * LPR; it += G::NTHR) {
+        const int row = HR0 + (it >> LSH), g = G0 + (it & (LPR - 1));
+        if (g < G1) {
+            float *rowp = lds + row * G::LW + G::PADC + 4 * g;
+            const lds_cv_f32x4 *rp4 = (const lds_cv_f32x4 *)rowp;
+            float v[4 * (MH - ML + 1)];
+#pragma unroll
+            for (int m = ML; m <= MH; m++) {
+                const f32x4 t = rp4[m];
+                v[4 * (m - ML) + 0] = t.x; v[4 * (m - ML) + 1] = t.y; v[4 * (m - ML) + 2] = t.z; v[4 * (m - ML) + 3] = t.w;
+            }
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k] = fmaf(tw.w[i], v[(-R - 4 * ML) + k + i], acc[k]);
+            }
+            *reinterpret_cast<float4 *>(rowp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    __syncthreads();
+    // vertical pass: ONE item (4 columns x RBV rows) per thread, results held in registers until every thread has read its
+    // window; RBV = the fewest rows per item that still make one round (more threads busy: a small octave is one workgroup per CU)
+    constexpr int VR0 = G::HP - MC, VROWS = G::T + 2 * MC;
+    constexpr int RBV = VROWS * LPR <= G::NTHR ? 1 : ((VROWS + 1) / 2 * LPR <= G::NTHR ? 2 : 4), NRG = (VROWS + RBV - 1) / RBV;
+    static_assert(NRG * LPR <= G::NTHR && VR0 - R >= 0 && VR0 + RBV * NRG + R <= G::LH, "one round");
+    const int g = G0 + (tid & (LPR - 1)), rgi = tid >> LSH;
+    const bool vact = rgi < NRG && g < G1;
+    float4 acc[RBV];
+    if (vact) {
+        const float *colp = lds + (VR0 + RBV * rgi - R) * G::LW + G::PADC + 4 * g;
+#pragma unroll
+        for (int rr = 0; rr < RBV; rr++) acc[rr] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int k = 0; k < RBV + 2 * R; k++) {
+            const float4 v = *reinterpret_cast<const float4 *>(colp + k * G::LW);
+#pragma unroll
+            for (int rr = 0; rr < RBV; rr++) {
+                const int i = k - rr;
+                if (i >= 0 && i < NT) {
+                    acc[rr].x = fmaf(tw.w[i], v.x, acc[rr].x);
+                    acc[rr].y = fmaf(tw.w[i], v.y, acc[rr].y);
+                    acc[rr].z = fmaf(tw.w[i], v.z, acc[rr].z);
+                    acc[rr].w = fmaf(tw.w[i], v.w, acc[rr].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RBV; rr++) asm volatile("" : "+v"(acc[rr].x), "+v"(acc[rr].y), "+v"(acc[rr].z), "+v"(acc[rr].w));
+        // the tile itself goes to the layer in global memory (w % 4 == 0: a float4 is inside the image or outside it)
+        const int gx = x0 - G::HP + 4 * g;
+        if (4 * g >= G::HP && 4 * g < G::HP + G::T && gx < w) {
+#pragma unroll
+            for (int rr = 0; rr < RBV; rr++) {
+                const int ry = VR0 + RBV * rgi + rr, gy = y0 - G::HP + ry;
+                if (ry < G::HP || ry >= G::HP + G::T || gy >= h) continue;
+                *reinterpret_cast<float4 *>(out + (size_t)gy * w + gx) = acc[rr];
+                if (do_dec && (gy & 1) == 0 && (gy >> 1) < h2) {      // next octave's layer 0 (NearestNeighborDownScale.metal:15-22)
+                    float *o2 = dec_out + (size_t)(gy >> 1) * w2 + (gx >> 1);
+                    if ((gx >> 1) + 0 < w2) o2[0] = acc[rr].x;
+                    if ((gx >> 1) + 1 < w2) o2[1] = acc[rr].z;
+                }
+            }
+        }
+    }
+    if (LAST) return;
+    __syncthreads();
+    if (vact) {
+        float *colp = lds + (VR0 + RBV * rgi) * G::LW + G::PADC + 4 * g;
+#pragma unroll
+        for (int rr = 0; rr < RBV; rr++) *reinterpret_cast<float4 *>(colp + rr * G::LW) = acc[rr];
+    }
+    __syncthreads();
+    if (border && MC > 0) {                                  // uniform: the region reaches past an image border
+        // Cells outside the image <- their mirrored positions: columns first (on every row), then whole rows (corners then hold
+        // the value mirrored both ways).  Only the MC cells next to a border can feed an output; a cell further out (partial
+        // last tiles) keeps whatever the passes left there.
+        constexpr int C0 = G::HP - MC, C1 = G::HP + G::T + MC, NV = C1 - C0, MCD = MC > 0 ? MC : 1;
+        const int cz = G::HP - x0, cw = w - (x0 - G::HP);   // region column of image column 0 / of the first column right of the image
+        const int rz = G::HP - y0, rh = h - (y0 - G::HP);
+        if (cz > C0 || cw < C1) {
+            for (int idx = tid; idx < NV * MCD; idx += G::NTHR) {
+                const int r = C0 + idx / MCD, j = idx % MCD;
+                float *rowp = lds + r * G::LW + G::PADC;
+                if (cz - 1 - j >= C0) rowp[cz - 1 - j] = rowp[cz + j];
+                if (cw + j < C1) rowp[cw + j] = rowp[cw - 1 - j];
+            }
+            __syncthreads();
+        }
+        if (rz > C0 || rh < C1) {
+            for (int idx = tid; idx < NV * MCD; idx += G::NTHR) {
+                const int j = idx / NV, cc = C0 + idx % NV;
+                float *colp = lds + G::PADC + cc;
+                if (rz - 1 - j >= C0) colp[(rz - 1 - j) * G::LW] = colp[(rz + j) * G::LW];
+                if (rh + j < C1) colp[(rh + j) * G::LW] = colp[(rh - 1 - j) * G::LW];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int T_, int NTHR_, int RA, int RB, int RC>
+__global__ __launch_bounds__(NTHR_) void blur_chain_kernel(float *__restrict__ layers /* the octave's layer 0, frame 0 */, int w, int h,
+                                                           size_t frame_stride, size_t layer_stride, int first /* input layer */, ChainWeights wts,
+                                                           int n_frames, int dec_layer /* the layer that also emits the next octave's layer 0, or 0 */,
+                                                           Decimate dec) {
+    using G = ChainGeom<T_, NTHR_, RA, RB, RC>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int tx = (w + G::T - 1) / G::T, ty = (h + G::T - 1) / G::T;
+    const int total = tx * ty * n_frames;
+    const int per_xcd = (total + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // XCD-aware 1-D order, see blur2_kernel
+    if (t >= total) return;
+    const int frame = t / (tx * ty);
+    const int rem = t - frame * (tx * ty);
+    const int by = rem / tx, bx = rem - by * tx;
+    const int x0 = bx * G::T, y0 = by * G::T;
+    float *__restrict__ base = layers + (size_t)frame * frame_stride + (size_t)first * layer_stride;
+    float *__restrict__ dec_out = dec.dst ? dec.dst + (size_t)frame * dec.frame_stride : nullptr;
+    const bool border = x0 - G::HP < 0 || y0 - G::HP < 0 || x0 + G::T + G::HP > w || y0 + G::T + G::HP > h;
+    {   // input layer -> region, mirror extension by row (symm) and by float4 (load_quad_mirrored); every load before the first LDS store
+        constexpr int Q = G::RW / 4, NB = (G::RW * Q + G::NTHR - 1) / G::NTHR;
+        f32x4 buf[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int idx = min(tid + b * G::NTHR, G::RW * Q - 1);
+            const int row = idx / Q, q = idx - row * Q;
+            const float *rowp = base + (size_t)min(max(symm(y0 - G::HP + row, h), 0), h - 1) * w;
+            buf[b] = load_quad_mirrored(rowp, x0 - G::HP + 4 * q, w);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int idx = min(tid + b * G::NTHR, G::RW * Q - 1);
+            const int row = idx / Q, q = idx - row * Q;
+            *reinterpret_cast<f32x4 *>(lds + row * G::LW + G::PADC + 4 * q) = buf[b];
+        }
+    }
+    __syncthreads();
+    constexpr int M0 = G::HP, M1 = M0 - RA, M2 = M1 - RB;
+    chain_layer<G, RA, M0, RB == 0>(lds, wts.l[0], base + 1 * layer_stride, w, h, x0, y0, border, dec_layer == first + 1, dec_out, dec.w2, dec.h2);
+    if constexpr (RB > 0)
+        chain_layer<G, RB, M1, RC == 0>(lds, wts.l[1], base + 2 * layer_stride, w, h, x0, y0, border, dec_layer == first + 2, dec_out, dec.w2, dec.h2);
+    if constexpr (RC > 0)
+        chain_layer<G, RC, M2, true>(lds, wts.l[2], base + 3 * layer_stride, w, h, x0, y0, border, dec_layer == first + 3, dec_out, dec.w2, dec.h2);
 }
 
 // Shipping geometry (tools/ubench/blur_variants.hip on 8 x 3840x2160, MI355X): 128 x 32 tiles, 256

@@ -103,6 +103,7 @@ struct siftmi_ctx {
     int32_t *d_bucket_src = nullptr, *d_row_count = nullptr, *d_row_start = nullptr;   // keypoint sort (kp_row_* kernels)
     unsigned char *d_act = nullptr;           // DoG activity flags [B][octave][nspo][h][ncell] written by the marching blur
     long long march_min_blocks = 2000;
+    long long chain_max_tiles = 0;            // blur_chain_kernel for octaves of at most this many tiles (0 = never)
     size_t act_off[MAX_OCT] = {0}, act_frame = 0;
     int act_ncell[MAX_OCT] = {0};
     bool act_valid[MAX_OCT] = {false};        // this sub-batch's flags of the octave are complete (all its layers used the marching blur)
@@ -240,6 +241,7 @@ extern "C" int siftmi_device_count(void) {
 
 static void retire_exec(hipGraphExec_t exec);
 
+static hipError_t prepare_blur_chain();
 static void free_ctx(siftmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -291,6 +293,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     c->device = hip_device;
     c->n_oct = cfg->n_octaves; c->nspo = cfg->nspo; c->B = cfg->max_batch;
     c->march_min_blocks = cfg->blur_march_min_blocks > 0 ? cfg->blur_march_min_blocks : 2000;
+    c->chain_max_tiles = cfg->blur_chain_max_tiles > 0 ? cfg->blur_chain_max_tiles : (cfg->blur_chain_max_tiles == 0 ? 256 : 0);
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_launches, 0, sizeof(c->t_launches));
     memset(c->t_blur_ms, 0, sizeof(c->t_blur_ms)); memset(c->t_blur_launches, 0, sizeof(c->t_blur_launches));
     const int W = cfg->width, H = cfg->height, nspo = cfg->nspo, NG = nspo + 3;
@@ -362,6 +365,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
 
     hipError_t e = hipSetDevice(hip_device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && c->chain_max_tiles > 0) e = prepare_blur_chain();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
     for (int i = 0; i < 2; i++) {
@@ -529,8 +533,15 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
         using Gm = typename S::G;
         const int total = ((w + Gm::TW - 1) / Gm::TW) * ((h + Gm::TH - 1) / Gm::TH) * nf;
         dim3 grid(((total + 7) / 8) * 8, 1, 1);          // XCD-aware 1-D tile order, see blur2_kernel
+        if constexpr (!SEED) {
+            if (act.dst) {
+                hipLaunchKernelGGL((blur2_kernel<R, S::TH, S::NTHR, 4, S::RB, false, 1, 0, true, DEC, true>), grid, dim3(S::NTHR), Gm::lds_bytes_act, st, src, dst, w,
+                                   h, c->frame_stride, c->frame_stride, wt, seed, nf, dec, act);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((blur2_kernel<R, S::TH, S::NTHR, 4, S::RB, SEED, 1, 0, true, DEC>), grid, dim3(S::NTHR),
-                           SEED ? Gm::seed_lds_bytes : Gm::lds_bytes, st, src, dst, w, h, c->frame_stride, c->frame_stride, wt, seed, nf, dec);
+                           SEED ? Gm::seed_lds_bytes : Gm::lds_bytes, st, src, dst, w, h, c->frame_stride, c->frame_stride, wt, seed, nf, dec, act);
     }
     return hipGetLastError();
 }
@@ -554,6 +565,55 @@ static hipError_t launch_blur(siftmi_ctx *c, hipStream_t st, int radius, const f
 #undef CASE_R
         default: return hipErrorInvalidValue;
     }
+}
+
+// Small launches (a frame or two): layers 1-3 and 4-5 of an octave from one launch each (blur_chain_kernel).  Default schedule
+// only -- the radii are template parameters.  64 x 64 tiles when that still makes two workgroups per CU, 32 x 32 below.
+static int chain_tile(const siftmi_ctx *c, int o, int nf) {            // 0 = this octave goes layer by layer
+    if (c->chain_max_tiles <= 0 || c->nspo != 3) return 0;
+    static const int want[5] = {11, 15, 17, 21, 27};
+    for (int s = 0; s < 5; s++) if (c->taps[s] != want[s]) return 0;
+    const int w = c->ow[o], h = c->oh[o];
+    if ((w & 3) != 0 || w < 64 || h < 64 || uses_march(c, w, h, nf)) return 0;
+    const long long t64 = (long long)((w + 63) / 64) * ((h + 63) / 64) * nf;
+    if (t64 > c->chain_max_tiles) return 0;
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_CHAIN_T64_MIN")) return t64 >= atoll(e) ? 64 : 32;
+#endif
+    return t64 >= 512 ? 64 : 32;
+}
+// The tile kernel writes the DoG activity flags too when the octave is large enough for the flagged-row scan to pay for them (one
+// 1920x1080 frame: octave 0's scan is 50-70 us of full rows against the ~10 % the flags add to three of its layers)
+static bool tile_flags(const siftmi_ctx *c, int o, int nf) {
+    long long min_px = 1500000;
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_TILE_ACT_MIN_PX")) min_px = atoll(e);
+#endif
+    return (long long)c->ow[o] * c->oh[o] * nf >= min_px;
+}
+template <int T, int NTHR, int RA, int RB, int RC>
+static hipError_t launch_chain_t(siftmi_ctx *c, hipStream_t st, float *layer0, int w, int h, int nf, int first, int dec_layer, const Decimate &dec) {
+    using G = ChainGeom<T, NTHR, RA, RB, RC>;
+    ChainWeights wts;
+    const int n = (RA > 0) + (RB > 0) + (RC > 0);
+    for (int s = 0; s < n; s++) wts.l[s] = c->layer_w[first + s];
+    for (int s = n; s < 3; s++) wts.l[s] = c->layer_w[first];
+    const int total = ((w + G::T - 1) / G::T) * ((h + G::T - 1) / G::T) * nf;
+    hipLaunchKernelGGL((blur_chain_kernel<T, NTHR, RA, RB, RC>), dim3(((total + 7) / 8) * 8), dim3(G::NTHR), G::lds_bytes, st, layer0, w, h, c->frame_stride,
+                       (size_t)w * h, first, wts, nf, dec_layer, dec);
+    return hipGetLastError();
+}
+static hipError_t prepare_blur_chain() {                 // once per device, outside any stream capture: more dynamic LDS than the 64 KB default
+    return hipFuncSetAttribute((const void *)blur_chain_kernel<64, 1024, 10, 13, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)ChainGeom<64, 1024, 10, 13, 0>::lds_bytes);
+}
+// layers first + 1 ... of octave layer0's octave; first = 0: layers 1-3, first = 3: layers 4-5
+static hipError_t launch_blur_chain(siftmi_ctx *c, hipStream_t st, int tile, float *layer0, int w, int h, int nf, int first, int dec_layer, const Decimate &dec) {
+    if (first == 0)
+        return tile == 64 ? launch_chain_t<64, 1024, 5, 7, 8>(c, st, layer0, w, h, nf, first, dec_layer, dec)
+                          : launch_chain_t<32, 256, 5, 7, 8>(c, st, layer0, w, h, nf, first, dec_layer, dec);
+    return tile == 64 ? launch_chain_t<64, 1024, 10, 13, 0>(c, st, layer0, w, h, nf, first, dec_layer, dec)
+                      : launch_chain_t<32, 256, 10, 13, 0>(c, st, layer0, w, h, nf, first, dec_layer, dec);
 }
 
 static float *gauss_ptr(siftmi_ctx *c, int o, int s) {
@@ -649,10 +709,27 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     for (int o = 0; o < c->n_oct; o++) {
         hipStream_t next = cur;
         // DoG activity flags for the extrema scan: only when every layer of this octave goes through the marching blur
-        c->act_valid[o] = !c->cfg.count_raw_extrema && c->ow[o] >= 3 && c->oh[o] >= 3 && uses_march(c, c->ow[o], c->oh[o], nf);
+        const int chain = chain_tile(c, o, nf);
+        c->act_valid[o] = !c->cfg.count_raw_extrema && c->ow[o] >= 3 && c->oh[o] >= 3 &&
+                          (uses_march(c, c->ow[o], c->oh[o], nf) || (!chain && tile_flags(c, o, nf)));
         if (o == 0 && first_of_call) c->raw_exact = true;
         if (c->act_valid[o]) c->raw_exact = false;
-        for (int s = 1; s < NG; s++) {
+        if (chain) {                                           // layers 1-3 (and the next octave's layer 0), then layers 4-5: two launches
+            Decimate dec = nodec;
+            if (o + 1 < c->n_oct) { dec.dst = gauss_ptr(c, o + 1, 0); dec.frame_stride = c->frame_stride; dec.w2 = c->ow[o + 1]; dec.h2 = c->oh[o + 1]; }
+            t_begin(c, SIFTMI_T_BLUR, o * 16 + 1);
+            HIP_TRY(launch_blur_chain(c, cur, chain, gauss_ptr(c, o, 0), c->ow[o], c->oh[o], nf, 0, dec.dst ? c->nspo : 0, dec));
+            t_end(c);
+            if (fork && o + 1 < c->n_oct) {
+                HIP_TRY(hipEventRecord(c->ev_fork[o], cur));
+                next = c->oct_stream[o + 1];
+                HIP_TRY(hipStreamWaitEvent(next, c->ev_fork[o], 0));
+            }
+            t_begin(c, SIFTMI_T_BLUR, o * 16 + 4);
+            HIP_TRY(launch_blur_chain(c, cur, chain, gauss_ptr(c, o, 0), c->ow[o], c->oh[o], nf, 3, 0, nodec));
+            t_end(c);
+        }
+        for (int s = 1; s < NG && !chain; s++) {
             Decimate dec = nodec;
             if (s == c->nspo && o + 1 < c->n_oct) {
                 dec.dst = gauss_ptr(c, o + 1, 0); dec.frame_stride = c->frame_stride; dec.w2 = c->ow[o + 1]; dec.h2 = c->oh[o + 1];

@@ -57,8 +57,9 @@ def main():
             max_oct += 1
         no = int(rng.integers(1, max_oct + 1))
         kind, img = make_image(rng, w, h)
-        # blur / extrema code path: default (tile blur, full scan), marching blur + flagged-row extrema scan, marching blur only
-        mode = [{}, {"blur_march_min_blocks": 1}, {"blur_march_min_blocks": 1, "count_raw_extrema": 1}][int(rng.integers(0, 3))]
+        # blur / extrema code path: default (tile blur or, where it applies, the multi-layer chain kernel; full scan), the chain kernel
+        # off, marching blur + flagged-row extrema scan, marching blur only
+        mode = [{}, {}, {"blur_chain_max_tiles": -1}, {"blur_march_min_blocks": 1}, {"blur_march_min_blocks": 1, "count_raw_extrema": 1}][int(rng.integers(0, 5))]
         tag = "case %d: %dx%d octaves %d nspo %d %s %s" % (case, w, h, no, nspo, kind, mode or "default")
         try:
             try:
