@@ -52,6 +52,8 @@ def main():
             w, h = int(rng.integers(700, 2100)), int(rng.integers(24, 160))         # wide strips
         elif rng.random() < 0.15:
             w, h = int(rng.integers(24, 160)), int(rng.integers(700, 2100))         # tall strips
+        elif rng.random() < 0.12:
+            w, h = int(rng.integers(1100, 2000)), int(rng.integers(700, 1100))      # a single large frame: tile blur with activity flags, flagged-row scan
         max_oct = 1
         while max_oct < 7 and min(2 * w, 2 * h) >> max_oct >= 12:
             max_oct += 1
