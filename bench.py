@@ -182,11 +182,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = node_rank = int(os.environ.get("LOCAL_RANK", "0"))      # node_rank: position on the node (who builds); local_rank: HIP device index
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if torch.cuda.device_count() == 1 and local_rank > 0:
+        local_rank = 0                                      # a launcher that shows every rank its own GPU only (HIP_VISIBLE_DEVICES per rank)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: local rank %d but only %d HIP device(s) visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -203,7 +205,7 @@ def main():
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
 
     import __graft_entry__ as ge
-    if local_rank == 0:                                     # one build per node; the others load the finished library
+    if node_rank == 0:                                      # one build per node; the others load the finished library
         ge.build()
     if world > 1:
         dist.barrier()
