@@ -336,8 +336,9 @@ def main():
                 if n:
                     radius = len(eng.weights(layer)) // 2
                     nbytes = eng.blur_algorithmic_bytes(o) * eng.max_batch
-                    shapes["o%d_l%d" % (o, layer)] = {"kernel": ("blur_ring_kernel<%d, ...>" if marching else "blur2_kernel<%d, ...>") % radius,
-                                                     "decimating": layer == NSPO and o + 1 < N_OCT, "activity_flags": bool(marching and 2 <= layer <= NSPO + 1),
+                    kind = eng.blur_layer_kind(o, layer)
+                    shapes["o%d_l%d" % (o, layer)] = {"kernel": "%s<%d, ...>" % (kind["kernel"], radius),
+                                                     "decimating": layer == NSPO and o + 1 < N_OCT, "activity_flags": kind["activity_flags"],
                                                      "launches": n, "avg_launch_us": round(ms / n * 1e3, 2),
                                                      "GBps": round(nbytes / (ms / n * 1e-3) / 1e9, 1)}
         per_layer = {}

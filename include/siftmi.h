@@ -419,7 +419,8 @@ int siftmi_reset_timings(siftmi_ctx *ctx);
 int siftmi_get_timings(siftmi_ctx *ctx, double *ms /*[SIFTMI_T_COUNT]*/, int64_t *launches /*[SIFTMI_T_COUNT]*/);
 /* the SIFTMI_T_BLUR time split by (octave, layer 1..nspo+2): accumulated ms and launch count of that layer's blur launches
    since the last reset -- one kernel instantiation and grid size each, so that a rocprofv3 kernel trace of the same command
-   can be compared launch shape by launch shape; *marching = 1 if those launches use blur_ring_kernel, 0 for blur2_kernel */
+   can be compared launch shape by launch shape; *marching: bit 0 = those launches use blur_ring_kernel (else blur2_kernel), bit 1 = they
+   also write the extrema scan's activity flags, bit 2 = the octave's layers come from blur_chain_kernel (1-3 under layer 1, 4-5 under 4) */
 int siftmi_get_blur_layer_timings(siftmi_ctx *ctx, int octave, int layer, double *ms, int64_t *launches, int32_t *marching);
 /* algorithmic bytes one blur launch of `octave` moves for ONE frame: 8 B per octave pixel */
 int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *ctx, int octave);

@@ -318,7 +318,13 @@ class Engine:
         """(accumulated ms, launches, uses the marching kernel) of the blur launches of (octave, layer) since reset_timings."""
         ms, n, m = C.c_double(), C.c_int64(), C.c_int32()
         _capi.check(self.L.siftmi_get_blur_layer_timings(self.h, o, layer, C.byref(ms), C.byref(n), C.byref(m)))
-        return ms.value, n.value, bool(m.value)
+        return ms.value, n.value, bool(m.value & 1)
+
+    def blur_layer_kind(self, o, layer):
+        """Which kernel the last call used for (octave, layer) and whether it wrote the extrema scan's activity flags."""
+        ms, n, m = C.c_double(), C.c_int64(), C.c_int32()
+        _capi.check(self.L.siftmi_get_blur_layer_timings(self.h, o, layer, C.byref(ms), C.byref(n), C.byref(m)))
+        return {"kernel": "blur_chain_kernel" if m.value & 4 else ("blur_ring_kernel" if m.value & 1 else "blur2_kernel"), "activity_flags": bool(m.value & 2)}
 
     def blur_algorithmic_bytes(self, o):
         return int(self.L.siftmi_blur_algorithmic_bytes(self.h, o))

@@ -513,6 +513,11 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 // 0.454 -> 0.445; nothing at R = 10 and 13 (0.511 / 0.607 either way, also with 168 registers per lane) -- those layers sit at
 // the FMA issue rate three waves per SIMD reach (tools/ubench/ubench_valu: 3.4 / 2.9 / 2.7 cycles per v_fma_f32 at 2 / 4 / 8
 // waves), not at LDS latency.  On for R <= 8.
+// VM (round 3 experiment, tools/ubench only; 0 in the library): the vertical pass on the matrix cores.  An f32 MFMA is a k-ordered
+// fmaf chain, so tile = T (banded tap matrix) x window gives every output its 2R + 1 taps in the reference's order between exact
+// zeros: bit-identical.  1 = v_mfma_f32_4x4x1 (16 blocks, four 4-row chains per wavefront), 2 = v_mfma_f32_16x16x1 (4 blocks).
+// Both slower than the vector form (profiles/blur_variants_r03_mfma_vertical.log): the f32 matrix rate IS the vector rate, and
+// the other wavefronts' horizontal passes do not speed up beside the MFMAs.
 template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12),
           bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */, int VM = 0>
 __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,

@@ -1585,7 +1585,11 @@ extern "C" int siftmi_get_blur_layer_timings(siftmi_ctx *c, int o, int layer, do
     t_collect(c);
     if (ms) *ms = c->t_blur_ms[o][layer];
     if (launches) *launches = c->t_blur_launches[o][layer];
-    if (marching) *marching = uses_march(c, c->ow[o], c->oh[o], std::min(c->B, std::max(c->last_frames, 1))) ? 1 : 0;
+    if (marching) {                                        // bit 0: blur_ring_kernel; bit 1: the launch writes activity flags; bit 2: blur_chain_kernel
+        const int nf = std::min(c->B, std::max(c->last_frames, 1));
+        const bool march = uses_march(c, c->ow[o], c->oh[o], nf), chain = chain_tile(c, o, nf) != 0;
+        *marching = (march ? 1 : 0) | ((c->act_valid[o] && layer >= 2 && layer <= c->nspo + 1) ? 2 : 0) | (chain ? 4 : 0);
+    }
     return SIFTMI_OK;
 }
 extern "C" int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *c, int o) {
