@@ -72,7 +72,7 @@ for key in sorted(fetch, key=lambda k: -k[1]):
     kname, grid = key
     f, wv = sorted(fetch[key]), sorted(write.get(key, [0.0]))
     fm, wm = f[len(f) // 2], wv[len(wv) // 2]
-    m = re.search(r"blur_ring_kernel<(\d+), \d+, \d+, (true|false), (true|false), \d+, (-?\d+)(?:, (?:true|false)){0,2}>", kname)
+    m = re.search(r"blur_ring_kernel<(\d+), \d+, \d+, (true|false), (true|false), \d+, (-?\d+)(?:, (?:true|false)){0,2}(?:, \d+)?>", kname)
     hbm = (cal["FETCH_SIZE"] or 2.0) * fm * 1024 + (cal["WRITE_SIZE"] or 1.0) * wm * 1024
     res.append({"kernel": kname.replace("void siftmi::", ""), "grid": grid, "launches_sampled": len(f), "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm,
                 "hbm_bytes_per_launch_corrected": hbm, "radius": int(m.group(1)) if m else None, "seed": bool(m and int(m.group(4)) >= 0),
