@@ -549,8 +549,8 @@ __global__ __launch_bounds__(1024) void kp_row_sort_small_kernel(PyramidDesc P, 
                                                                 const unsigned long long *__restrict__ kp_keys, const int32_t *__restrict__ kp_count,
                                                                 int32_t *__restrict__ row_count /* in: counts, out: zeros */,
                                                                 unsigned long long *__restrict__ bucket_keys, int32_t *__restrict__ bucket_src,
-                                                                KeypointRec *__restrict__ kp_sorted) {
-    extern __shared__ int rows[];                          // [n_rows] bucket starts, then ends
+                                                                KeypointRec *__restrict__ kp_sorted, int n_lds /* keypoints the LDS behind rows[] holds */) {
+    extern __shared__ int rows[];                          // [n_rows] bucket starts, then ends; then n_lds keys (u64) and source indices
     __shared__ int wsum[16];
     const int group = group_index(P, blockIdx.x), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n_rows = (P.nspo + 2) * P.h[o];
@@ -590,6 +590,28 @@ __global__ __launch_bounds__(1024) void kp_row_sort_small_kernel(PyramidDesc P, 
         }
     }
     __syncthreads();
+    if (n <= n_lds) {
+        // the usual case of these launches (a few hundred to a few thousand keypoints): bucketed keys and source indices stay
+        // in LDS -- two global write -> barrier -> read round trips fewer on a chain that is bound by exactly such latencies
+        unsigned long long *lkeys = reinterpret_cast<unsigned long long *>(rows + ((n_rows + 1) & ~1));
+        int *lsrc = reinterpret_cast<int *>(lkeys + n_lds);
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const unsigned long long key = kp_keys[base + i];
+            const int slot = atomicAdd(&rows[(unsigned int)(key >> 32) / w], 1);
+            lkeys[slot] = key;
+            lsrc[slot] = i;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 1024) {
+            const unsigned long long key = lkeys[j];
+            const unsigned int row = (unsigned int)(key >> 32) / w;
+            const int b0 = row ? rows[row - 1] : 0, b1 = rows[row];
+            int rank = b0;
+            for (int k = b0; k < b1; k++) rank += (lkeys[k] < key) ? 1 : 0;
+            kp_sorted[base + rank] = kp_tmp[base + lsrc[j]];
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += 1024) {          // scatter (as kp_row_scatter_kernel)
         const unsigned long long key = kp_keys[base + i];
         const int slot = atomicAdd(&rows[(unsigned int)(key >> 32) / w], 1);

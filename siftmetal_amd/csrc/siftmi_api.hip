@@ -780,8 +780,11 @@ static int run_refine(siftmi_ctx *c, hipStream_t st, int nf, int only_octave = -
     t_begin(c, SIFTMI_T_SORT);
     const size_t rows_bytes = only_octave >= 0 ? (size_t)(c->nspo + 2) * c->oh[only_octave] * sizeof(int32_t) : 0;
     if (only_octave >= 0 && rows_bytes <= 60 * 1024) {     // a per-octave chain of a forked graph: one launch instead of three
-        hipLaunchKernelGGL(kp_row_sort_small_kernel, dim3(groups), dim3(1024), rows_bytes, st, P, c->d_kp_tmp, c->d_keys, cnt(c, C_KP), c->d_row_count,
-                           c->d_bucket_keys, c->d_bucket_src, c->d_kp);
+        // LDS behind the row buckets: bucketed keys (8 B) and source indices (4 B) of up to n_lds keypoints (64 KB in all)
+        const size_t rows_al = (rows_bytes + 7) & ~(size_t)7;
+        const int n_lds = (int)std::min<size_t>(4096, (64 * 1024 - 256 - rows_al) / 12);
+        hipLaunchKernelGGL(kp_row_sort_small_kernel, dim3(groups), dim3(1024), rows_al + (size_t)n_lds * 12, st, P, c->d_kp_tmp, c->d_keys, cnt(c, C_KP),
+                           c->d_row_count, c->d_bucket_keys, c->d_bucket_src, c->d_kp, n_lds);
         HIP_TRY(hipGetLastError());
         t_end(c);
         return SIFTMI_OK;
