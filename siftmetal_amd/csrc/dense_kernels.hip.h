@@ -73,6 +73,10 @@ struct Activity {
     float thr;                      // 0.8 * dog_threshold (SIFTInterpolate.metal:208)
 };
 
+// Two int ranges cleared by the seed tile kernel on its way (the per-call counters and, for the per-octave chains of a
+// single-frame call, the keypoint sort's row buckets): a launch and a dependency gap fewer at the head of every small call.
+struct ZeroJob { int32_t *a; size_t na; int32_t *b; size_t nb; };
+
 struct SeedSource {                 // input frame description for the seed loader
     const unsigned char *pixels;    // frame 0
     size_t frame_stride;            // bytes between frames
@@ -211,9 +215,15 @@ struct Blur2Geom {
 template <int R, int TH_, int NTHR_, int HO_, int RB_, bool SEED, int MINW = 1, int KCH = 0, bool XCD = false, bool DEC = false, bool ACT = false>
 __global__ __launch_bounds__(NTHR_, MINW) void blur2_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                            size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt, SeedSource seed, int n_frames,
-                                                           Decimate dec, Activity act) {
+                                                           Decimate dec, Activity act, ZeroJob zj) {
     using G = Blur2Geom<R, TH_, NTHR_, HO_, RB_>;
     constexpr int NTHR = G::NTHR;
+    if (SEED && zj.a) {                                    // nothing reads these before the kernels that follow the seed
+        const size_t gsz = (size_t)gridDim.x * gridDim.y * gridDim.z * NTHR;
+        const size_t gtid = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NTHR + threadIdx.x;
+        for (size_t i = gtid; i < zj.na; i += gsz) zj.a[i] = 0;
+        for (size_t i = gtid; i < zj.nb; i += gsz) zj.b[i] = 0;
+    }
     static_assert(!ACT || (!SEED && G::V_ITEMS == NTHR && NTHR % 64 == 0 && (G::LH * (G::TW / 4)) % 64 == 0), "ACT: whole wavefronts in both passes");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;

@@ -104,6 +104,7 @@ struct siftmi_ctx {
     unsigned char *d_act = nullptr;           // DoG activity flags [B][octave][nspo][h][ncell] written by the marching blur
     long long march_min_blocks = 2000;
     long long chain_max_tiles = 0;            // blur_chain_kernel for octaves of at most this many tiles (0 = never)
+    ZeroJob zero_job{nullptr, 0, nullptr, 0}; // counters to clear at the head of a call, handed to the seed tile kernel (run_dense_detect)
     size_t act_off[MAX_OCT] = {0}, act_frame = 0;
     int act_ncell[MAX_OCT] = {0};
     bool act_valid[MAX_OCT] = {false};        // this sub-batch's flags of the octave are complete (all its layers used the marching blur)
@@ -536,12 +537,14 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
         if constexpr (!SEED) {
             if (act.dst) {
                 hipLaunchKernelGGL((blur2_kernel<R, S::TH, S::NTHR, 4, S::RB, false, 1, 0, true, DEC, true>), grid, dim3(S::NTHR), Gm::lds_bytes_act, st, src, dst, w,
-                                   h, c->frame_stride, c->frame_stride, wt, seed, nf, dec, act);
+                                   h, c->frame_stride, c->frame_stride, wt, seed, nf, dec, act, ZeroJob{nullptr, 0, nullptr, 0});
                 return hipGetLastError();
             }
         }
+        ZeroJob zj{nullptr, 0, nullptr, 0};
+        if (SEED) { zj = c->zero_job; c->zero_job = ZeroJob{nullptr, 0, nullptr, 0}; }       // the seed tile kernel clears the call's counters on its way
         hipLaunchKernelGGL((blur2_kernel<R, S::TH, S::NTHR, 4, S::RB, SEED, 1, 0, true, DEC>), grid, dim3(S::NTHR),
-                           SEED ? Gm::seed_lds_bytes : Gm::lds_bytes, st, src, dst, w, h, c->frame_stride, c->frame_stride, wt, seed, nf, dec, act);
+                           SEED ? Gm::seed_lds_bytes : Gm::lds_bytes, st, src, dst, w, h, c->frame_stride, c->frame_stride, wt, seed, nf, dec, act, zj);
     }
     return hipGetLastError();
 }
@@ -697,13 +700,17 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     // third launch of a serial graph on (ROCm 7.2; tests/test_gpu_parity.py::test_graph_replays_stay_correct).
     // the first sub-batch of a call also clears the running totals (PackState) that sit behind the counters
     const size_t n_cnt = 5 * (size_t)c->B * c->n_oct + (first_of_call ? sizeof(PackState) / sizeof(int32_t) : 0);
-    if (fork)                                              // + the row buckets of the per-octave refine launches, in the same launch
-        hipLaunchKernelGGL(zero2_i32_kernel, dim3(64), dim3(256), 0, st, c->d_counters, n_cnt, c->d_row_count, (size_t)nf * c->P.row_frame);
-    else
-        hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters, n_cnt);
+    // (+ the row buckets of the per-octave refine launches of a forked call.)  The seed TILE kernel takes the job along; after a
+    // marching seed launch it is still pending and gets its own launch -- nothing before the extrema scans reads these ranges
+    c->zero_job = ZeroJob{c->d_counters, n_cnt, fork ? c->d_row_count : nullptr, fork ? (size_t)nf * c->P.row_frame : 0};
     t_begin(c, SIFTMI_T_SEED);
     HIP_TRY((launch_blur<true>(c, st, (c->seed_taps - 1) / 2, nullptr, gauss_ptr(c, 0, 0), c->ow[0], c->oh[0], nf, c->seed_w, seed, nodec)));
     t_end(c);
+    if (c->zero_job.a) {
+        if (fork) hipLaunchKernelGGL(zero2_i32_kernel, dim3(64), dim3(256), 0, st, c->d_counters, n_cnt, c->d_row_count, (size_t)nf * c->P.row_frame);
+        else hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters, n_cnt);
+        c->zero_job = ZeroJob{nullptr, 0, nullptr, 0};
+    }
     hipStream_t cur = st;
     bool joined[MAX_OCT] = {};
     for (int o = 0; o < c->n_oct; o++) {

@@ -20,19 +20,19 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/calib_$C -- $R/tools/ubench/pmc_calib 3840 2176 8 5 > $OUT/calib_$C.log 2>&1
 done
 python3 - <<PY
-import csv, glob, json, collections, re
+import csv, glob, json, collections, os, re
 out, tag = "$OUT", "$TAG"
 # --- kernel stats
-stats = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
-rows = list(csv.DictReader(open(stats[0]))) if stats else []
+stats = sorted(glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
+rows = list(csv.DictReader(open(stats[-1]))) if stats else []
 with open(out + "/rocprof_kernel_stats_%s.csv" % tag, "w") as f:
     if rows:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 # per launch shape (kernel name x grid): the kernel-trace rows of the same run grouped like bench.py's roofline.by_launch_shape
-trace = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)
+trace = sorted(glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 if trace:
     d = collections.defaultdict(list)
-    for r in csv.DictReader(open(trace[0])):
+    for r in csv.DictReader(open(trace[-1])):
         n = r["Kernel_Name"]
         short = (n[:n.index("(")] if "(" in n else n).replace("void siftmi::", "").replace("siftmi::", "")
         d[(short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -41,9 +41,9 @@ if trace:
         w.writerow(["kernel", "workgroups_x", "grid_y", "grid_z", "calls", "avg_us", "min_us", "max_us", "total_ms"])
         for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k[0], k[1], k[2], k[3], len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2), round(sum(v) / 1e6, 3)])
-pst = glob.glob(out + "/trace_pipelined/**/*kernel_stats.csv", recursive=True)
+pst = sorted(glob.glob(out + "/trace_pipelined/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if pst:
-    prow = list(csv.DictReader(open(pst[0])))
+    prow = list(csv.DictReader(open(pst[-1])))
     with open(out + "/rocprof_kernel_stats_%s_pipelined.csv" % tag, "w") as f:
         if prow:
             w = csv.DictWriter(f, fieldnames=list(prow[0].keys())); w.writeheader(); w.writerows(prow)
@@ -52,7 +52,8 @@ for r in rows[:16]:
 
 def collect(d, counter, want):
     vals = collections.defaultdict(list)
-    for f in glob.glob(out + "/" + d + "/**/*counter_collection.csv", recursive=True):
+    files = sorted(glob.glob(out + "/" + d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                                    # the newest pass only (a merged copy of this directory can hold older ones)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter or want not in r["Kernel_Name"]: continue
             vals[(r["Kernel_Name"].split("(")[0][-100:], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))

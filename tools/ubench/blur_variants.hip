@@ -77,7 +77,7 @@ static void bench_R(Ctx &c, float rho) {
 #define V2X(TH_, NTHR_, RB_, MINW_, KCH_) { using G = Blur2Geom<R, TH_, NTHR_, 4, RB_>; \
         const int total = ((c.w + G::TW - 1) / G::TW) * ((c.h + G::TH - 1) / G::TH) * c.nf; \
         dim3 grid(((total + 7) / 8) * 8, 1, 1); \
-        run_variant("tile TH=" #TH_ " RB=" #RB_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec, noact); }); }
+        run_variant("tile TH=" #TH_ " RB=" #RB_ " XCD", c, R, [&] { hipLaunchKernelGGL((blur2_kernel<R, TH_, NTHR_, 4, RB_, false, MINW_, KCH_, true>), grid, dim3(NTHR_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, none, c.nf, nodec, noact, ZeroJob{nullptr, 0, nullptr, 0}); }); }
     V2X(32, 256, 4, 1, 0)
     // round 2: ring form
 #define VR(S_, CHR_, MINW_, DBG_) { using G = RingGeom<R, S_>; \
