@@ -242,7 +242,6 @@ extern "C" int siftmi_device_count(void) {
 
 static void retire_exec(hipGraphExec_t exec);
 
-static hipError_t prepare_blur_chain();
 static void free_ctx(siftmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -366,7 +365,6 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
 
     hipError_t e = hipSetDevice(hip_device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess && c->chain_max_tiles > 0) e = prepare_blur_chain();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
     for (int i = 0; i < 2; i++) {
@@ -570,8 +568,9 @@ static hipError_t launch_blur(siftmi_ctx *c, hipStream_t st, int radius, const f
     }
 }
 
-// Small launches (a frame or two): layers 1-3 and 4-5 of an octave from one launch each (blur_chain_kernel).  Default schedule
-// only -- the radii are template parameters.  64 x 64 tiles when that still makes two workgroups per CU, 32 x 32 below.
+// Small launches (a frame or two): layers 1-3 and 4-5 of an octave from one launch each (blur_chain_kernel), 32 x 32 tiles and 256
+// threads.  Default schedule only -- the radii are template parameters.  (64 x 64 tiles with 1024 threads, for octaves of >= 512
+// such tiles, were measured on a 1080p frame's octave 0: 60 + 81 us against 53 + 56 us for the five per-layer launches.)
 static int chain_tile(const siftmi_ctx *c, int o, int nf) {            // 0 = this octave goes layer by layer
     if (c->chain_max_tiles <= 0 || c->nspo != 3) return 0;
     static const int want[5] = {11, 15, 17, 21, 27};
@@ -579,11 +578,7 @@ static int chain_tile(const siftmi_ctx *c, int o, int nf) {            // 0 = th
     const int w = c->ow[o], h = c->oh[o];
     if ((w & 3) != 0 || w < 64 || h < 64 || uses_march(c, w, h, nf)) return 0;
     const long long t64 = (long long)((w + 63) / 64) * ((h + 63) / 64) * nf;
-    if (t64 > c->chain_max_tiles) return 0;
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_CHAIN_T64_MIN")) return t64 >= atoll(e) ? 64 : 32;
-#endif
-    return t64 >= 512 ? 64 : 32;
+    return t64 <= c->chain_max_tiles ? 32 : 0;
 }
 // The tile kernel writes the DoG activity flags too when the octave is large enough for the flagged-row scan to pay for them (one
 // 1920x1080 frame: octave 0's scan is 50-70 us of full rows against the ~10 % the flags add to three of its layers)
@@ -597,6 +592,7 @@ static bool tile_flags(const siftmi_ctx *c, int o, int nf) {
 template <int T, int NTHR, int RA, int RB, int RC>
 static hipError_t launch_chain_t(siftmi_ctx *c, hipStream_t st, float *layer0, int w, int h, int nf, int first, int dec_layer, const Decimate &dec) {
     using G = ChainGeom<T, NTHR, RA, RB, RC>;
+    static_assert(G::lds_bytes <= 64 * 1024, "default dynamic LDS limit");
     ChainWeights wts;
     const int n = (RA > 0) + (RB > 0) + (RC > 0);
     for (int s = 0; s < n; s++) wts.l[s] = c->layer_w[first + s];
@@ -606,17 +602,30 @@ static hipError_t launch_chain_t(siftmi_ctx *c, hipStream_t st, float *layer0, i
                        (size_t)w * h, first, wts, nf, dec_layer, dec);
     return hipGetLastError();
 }
-static hipError_t prepare_blur_chain() {                 // once per device, outside any stream capture: more dynamic LDS than the 64 KB default
-    return hipFuncSetAttribute((const void *)blur_chain_kernel<64, 1024, 10, 13, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)ChainGeom<64, 1024, 10, 13, 0>::lds_bytes);
-}
 // layers first + 1 ... of octave layer0's octave; first = 0: layers 1-3, first = 3: layers 4-5
-static hipError_t launch_blur_chain(siftmi_ctx *c, hipStream_t st, int tile, float *layer0, int w, int h, int nf, int first, int dec_layer, const Decimate &dec) {
-    if (first == 0)
-        return tile == 64 ? launch_chain_t<64, 1024, 5, 7, 8>(c, st, layer0, w, h, nf, first, dec_layer, dec)
-                          : launch_chain_t<32, 256, 5, 7, 8>(c, st, layer0, w, h, nf, first, dec_layer, dec);
-    return tile == 64 ? launch_chain_t<64, 1024, 10, 13, 0>(c, st, layer0, w, h, nf, first, dec_layer, dec)
-                      : launch_chain_t<32, 256, 10, 13, 0>(c, st, layer0, w, h, nf, first, dec_layer, dec);
+static hipError_t launch_blur_chain(siftmi_ctx *c, hipStream_t st, float *layer0, int w, int h, int nf, int first, int dec_layer, const Decimate &dec) {
+    if (first == 0) return launch_chain_t<32, 256, 5, 7, 8>(c, st, layer0, w, h, nf, first, dec_layer, dec);
+    return launch_chain_t<32, 256, 10, 13, 0>(c, st, layer0, w, h, nf, first, dec_layer, dec);
+}
+
+// A descriptor gets a whole workgroup on launches of at most this many octave-0 pixels ("a frame or two")
+static long long small_launch_pixels() {
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_COOP_PX")) return atoll(e);
+#endif
+    return 16ll * 1024 * 1024;
+}
+// The captured launch sequence forks into one chain per octave (run_dense_detect) unless a single frame's first octave is larger
+// than this.  Round 2 forked only "a frame or two" (<= 16 Mpixel per launch); measured in round 3 (tools/batch_size_sweep.py,
+// bench.py): 3 ... 16 frames of 1920x1080 per step 8-18 % faster forked, 64 frames 10.41 -> 9.98 ms per step with two steps in
+// flight (10.89 -> 10.40 one at a time: octave k's keypoint stages and scan run beside octave k+1's pyramid), the host-fed stream
+// 12.0 -> 10.8 ms; one 8192 x 8192 tile (268 Mpixel first octave) 6.4 -> 6.6 ms, hence the cap per frame.
+static bool fork_chains(const siftmi_ctx *c) {
+    long long max_px = 48ll * 1024 * 1024;
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_FORK_PX")) max_px = atoll(e);
+#endif
+    return c->n_oct > 1 && (long long)c->ow[0] * c->oh[0] <= max_px;
 }
 
 static float *gauss_ptr(siftmi_ctx *c, int o, int s) {
@@ -681,10 +690,10 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
 
 // Dense front end + extrema for nf frames (DifferenceOfGaussians.swift:346-406, SIFTOctave.swift:177-196):
 // seed -> per octave {layer blurs; the one writing layer nspo also emits the next octave's layer 0} -> extrema.
-// Octave o+1 depends on octave o only through that layer, so when `fork` is set (graph capture of a small
-// launch, e.g. ONE frame) the rest of octave o (its last layers and its extrema scan) stays on the current
-// stream while octave o+1 continues on another one; everything joins before refinement.  Large batches fill
-// the chip with every launch and gain nothing from this (tools/two_stream_probe.py), so they stay serial.
+// Octave o+1 depends on octave o only through that layer, so when `fork` is set (graph capture; fork_chains) the rest
+// of octave o (its last layers, its extrema scan and its keypoint stages) stays on the current stream while octave o+1
+// continues on another one; everything joins before the pack.  (Round 2 forked single frames only: a two-stream probe
+// of the DENSE stages of a 64-frame batch showed no gain.  With the keypoint stages on the chains a batch gains 4 %.)
 static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d_pixels, int format, size_t row_stride, size_t frame_stride,
                             bool fork, bool first_of_call) {
     const int NG = c->nspo + 3;
@@ -725,7 +734,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
             Decimate dec = nodec;
             if (o + 1 < c->n_oct) { dec.dst = gauss_ptr(c, o + 1, 0); dec.frame_stride = c->frame_stride; dec.w2 = c->ow[o + 1]; dec.h2 = c->oh[o + 1]; }
             t_begin(c, SIFTMI_T_BLUR, o * 16 + 1);
-            HIP_TRY(launch_blur_chain(c, cur, chain, gauss_ptr(c, o, 0), c->ow[o], c->oh[o], nf, 0, dec.dst ? c->nspo : 0, dec));
+            HIP_TRY(launch_blur_chain(c, cur, gauss_ptr(c, o, 0), c->ow[o], c->oh[o], nf, 0, dec.dst ? c->nspo : 0, dec));
             t_end(c);
             if (fork && o + 1 < c->n_oct) {
                 HIP_TRY(hipEventRecord(c->ev_fork[o], cur));
@@ -733,7 +742,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
                 HIP_TRY(hipStreamWaitEvent(next, c->ev_fork[o], 0));
             }
             t_begin(c, SIFTMI_T_BLUR, o * 16 + 4);
-            HIP_TRY(launch_blur_chain(c, cur, chain, gauss_ptr(c, o, 0), c->ow[o], c->oh[o], nf, 3, 0, nodec));
+            HIP_TRY(launch_blur_chain(c, cur, gauss_ptr(c, o, 0), c->ow[o], c->oh[o], nf, 3, 0, nodec));
             t_end(c);
         }
         for (int s = 1; s < NG && !chain; s++) {
@@ -822,7 +831,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     t_end(c);
     t_begin(c, SIFTMI_T_DESCRIBE);
     // a frame or two: fewer descriptors than wavefront slots -> one workgroup per descriptor (see descriptor_kernel)
-    if ((long long)nf * c->ow[0] * c->oh[0] <= 16ll * 1024 * 1024)
+    if ((long long)nf * c->ow[0] * c->oh[0] <= small_launch_pixels())
         hipLaunchKernelGGL(descriptor_kernel<true>, dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                            c->d_desc_f32);
     else
@@ -982,8 +991,7 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                // fork the octave chains only for small launches (the first octave has fewer tiles than ~4 per CU)
-                const bool fork = c->n_oct > 1 && (long long)std::min(c->B, (int)n_frames) * c->ow[0] * c->oh[0] <= 16ll * 1024 * 1024;
+                const bool fork = fork_chains(c);
                 rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
                                    (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals, fork);
                 e = hipStreamEndCapture(st, &graph);
