@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "64")), help="frames processed in lock-step per launch")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (cycled to fill the batch)")
     ap.add_argument("--march-min-blocks", type=int, default=0, help="siftmi_config.blur_march_min_blocks (0 = library default)")
+    ap.add_argument("--serial-graph", action="store_true", help="siftmi_config.graph_fork = -1: the captured launch sequence stays one chain, "
+                    "so that every kernel runs alone (per-kernel traces: tools/profile_round.sh)")
     ap.add_argument("--pipeline", type=int, default=2, choices=(1, 2),
                     help="steps in flight: 2 alternates consecutive steps between two contexts (two pyramids) on two streams")
     ap.add_argument("--no-cpu", action="store_true")
@@ -218,6 +220,8 @@ def main():
     frames_np = np.roll(frames_np, rank, axis=0)
     d_frames = smstream.DeviceFrames(frames_np, local_rank)      # HBM through siftmi_device_alloc / siftmi_memcpy
     tune = {"blur_march_min_blocks": args.march_min_blocks} if args.march_min_blocks > 0 else {}
+    if args.serial_graph:
+        tune["graph_fork"] = -1
     eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
     uid = None
     if use_dist:

@@ -90,7 +90,11 @@ typedef struct siftmi_config {
                                            4-5 from ONE launch each (single frames: fewer dependent launches per call).  0 = default
                                            (256: the 960x540 and 480x270 octaves of one 1920x1080 frame), -1 = off.  Default schedule only (nspo = 3,
                                            taps 11 ... 27), octave width a multiple of 4, at least 64 x 64 */
-    int32_t reserved[3];
+    int32_t graph_fork;                 /* the captured launch sequence of siftmi_detect_describe_batch_device forks into one chain per
+                                           octave (octave k's scan and keypoint stages beside octave k+1's pyramid): 0 = default (on,
+                                           unless a frame's first octave exceeds 48 Mpixel), 1 = always, -1 = never (every kernel
+                                           alone on the GPU: what a per-kernel profile wants) */
+    int32_t reserved[2];
 } siftmi_config;
 
 /* Replaces SIFTExtremaResult (Sources/MetalShaders/include/SIFTExtrema.h:14-18). */

@@ -625,6 +625,7 @@ static bool fork_chains(const siftmi_ctx *c) {
 #ifdef SIFTMI_EXPERIMENT
     if (const char *e = getenv("SIFTMI_EXP_FORK_PX")) max_px = atoll(e);
 #endif
+    if (c->cfg.graph_fork) return c->n_oct > 1 && c->cfg.graph_fork > 0;
     return c->n_oct > 1 && (long long)c->ow[0] * c->oh[0] <= max_px;
 }
 

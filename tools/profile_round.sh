@@ -10,8 +10,9 @@ rm -rf $OUT; mkdir -p $OUT
 # 1. per-kernel time of the bench command.  With two steps in flight (the default) kernels of the two contexts run
 #    concurrently and the trace's durations include the time they spend sharing the GPU; the per-kernel figures that
 #    bench.py's roofline object reports come from its one-step-at-a-time pass, so the trace they are compared with is
-#    taken with --pipeline 1 (every kernel alone on the GPU) and the trace of the default command is kept beside it.
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras --pipeline 1 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+#    taken with --pipeline 1 --serial-graph (one step at a time, the captured launch sequence not forked into per-octave
+#    chains: every kernel alone on the GPU) and the trace of the default command is kept beside it.
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras --pipeline 1 --serial-graph > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/bench_under_rocprof_pipelined.json 2> $OUT/bench_under_rocprof_pipelined.err
 # 2. HBM bytes of the blur kernel: the five octave-0 layer launches of the pipeline itself (8 frames per launch, one call),
 #    plus the calibration copy with the same access shapes and a known byte count (tools/ubench/pmc_calib.hip)
