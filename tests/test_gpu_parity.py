@@ -611,20 +611,25 @@ def test_graph_replays_stay_correct(sm, frames, lockstep):
     (ROCm 7.2, non-forked graphs), so later replays accumulated garbage.  Counters are now cleared by a kernel; every
     replay, synchronised and read back, must reproduce the host API's counts."""
     from siftmetal_amd import stream as smstream
-    w, h = 1280, 960                                    # 4 frames x 2560 x 1920 > 16 Mpx: the serial (non-forked) graph
+    w, h = 1280, 960
     batch = np.stack([blob_frame(w, h, i) for i in range(frames)])
-    eng = sm.Engine(w, h, n_octaves=4, max_batch=lockstep)
-    _, kc, _, dc = eng.detect_describe_batch(batch)
-    fs = smstream.FrameStream(eng, frames)
-    d = smstream.DeviceFrames(batch)
-    for launch in range(6):
-        fs.run(d)
-        fs.synchronize()
-        r = fs.results_host()
-        assert (r["n_keypoints"], r["n_descriptors"]) == (int(kc.sum()), int(dc.sum())), "launch %d" % launch
-        np.testing.assert_array_equal(r["counts"][0], kc)
-        np.testing.assert_array_equal(r["counts"][1], dc)
-    eng.close()
+    want = None
+    for fork in (0, -1, 1):                             # the captured sequence forked into per-octave chains (default), serial, forced
+        eng = sm.Engine(w, h, n_octaves=4, max_batch=lockstep, graph_fork=fork)
+        _, kc, _, dc = eng.detect_describe_batch(batch)
+        fs = smstream.FrameStream(eng, frames)
+        d = smstream.DeviceFrames(batch)
+        for launch in range(6):
+            fs.run(d)
+            fs.synchronize()
+            r = fs.results_host()
+            assert (r["n_keypoints"], r["n_descriptors"]) == (int(kc.sum()), int(dc.sum())), "launch %d" % launch
+            np.testing.assert_array_equal(r["counts"][0], kc)
+            np.testing.assert_array_equal(r["counts"][1], dc)
+        got = (r["keypoints"].tobytes(), r["descriptors"].tobytes())
+        assert want is None or got == want, "graph_fork = %d" % fork
+        want = got
+        fs.close(); d.close(); eng.close()
 
 
 # ------------------------------------------------------------------------------------------------
