@@ -467,12 +467,14 @@ static void t_collect(siftmi_ctx *c) {
 // Rows per chunk of the marching (ring) blur: a workgroup walks its 128-column strip down one chunk in steps of 32 rows and
 // pays 2R extra horizontally blurred rows for the chunk's prologue (20 % of a 128-row chunk at R = 13).  Tall octaves take
 // 256-row chunks (tools/ubench/blur_variants.hip, 32 x 3840x2160: 2-4 % faster than 128 at every radius; whole-height strips
-// are no faster and leave a worse tail); for 1920x1080 the shorter chunks win (more workgroups than resident slots).
+// are no faster and leave a worse tail); for 1920x1080 the shorter chunks win (more workgroups than resident slots): 128 rows
+// in round 2, 160 since the octave chains of a batch run side by side (round 3: 9.82 against 9.97 ms per step, three interleaved
+// pairs of runs; 192: 10.04).
 static int march_chunk_rows(int h) {
 #ifdef SIFTMI_EXPERIMENT
     if (const char *e = getenv(h >= 1600 ? "SIFTMI_EXP_CHUNK_BIG" : "SIFTMI_EXP_CHUNK_SMALL")) return atoi(e);
 #endif
-    return h >= 1600 ? 256 : 128;
+    return h >= 1600 ? 256 : 160;
 }
 
 // the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 2000)
