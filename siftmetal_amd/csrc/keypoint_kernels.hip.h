@@ -763,6 +763,10 @@ __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, 
 // One wavefront per keypoint; the (2r+1)^2 window is strided over the 64 lanes into a 36-bin LDS
 // histogram (u64 fixed point, see fix32_product); smoothing / peak search run on lanes 0..35 with shuffles.
 // ori_count[k] = -1 when the host-side border filter of the reference rejects the keypoint.
+// COOP (as descriptor_kernel): the four wavefronts of a workgroup share one keypoint -- on a frame or two there are fewer keypoints
+// than wavefront slots and a window of ~850 samples is 13 dependent rounds for one wavefront, 4 for a workgroup.  Same samples
+// into the same u64 fixed-point bins: bit-identical.
+template <bool COOP>
 __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectParams prm,
                                                          const KeypointRec *__restrict__ kps, const int32_t *__restrict__ kp_count,
                                                          int32_t *__restrict__ ori_count, float *__restrict__ ori_angles) {
@@ -772,14 +776,16 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
     constexpr int OCOPY = SIFTMI_ORI_NCOPY, OSTRIDE = ORI_BINS + 1;
     __shared__ unsigned long long hist_all[4][OCOPY * OSTRIDE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long *hist0 = hist_all[wv];
+    unsigned long long *hist0 = hist_all[COOP ? 0 : wv];
     unsigned long long *hist = hist0 + (lane & (OCOPY - 1)) * OSTRIDE;
+    constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one keypoint's window
+    const int lidx = COOP ? (int)threadIdx.x : lane;
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
     const int w = P.w[o], h = P.h[o];
     const float delta = P.delta[o], lambda = prm.lambda_ori;
     const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
-    for (int k = blockIdx.x * 4 + wv; k < n; k += gridDim.x * 4) {
+    for (int k = COOP ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wv); k < n; k += COOP ? (int)gridDim.x : (int)(gridDim.x * 4)) {
         const KeypointRec kp = kps[base + k];
         bool reject;
         {   // SIFTOctave.swift:303-329
@@ -789,14 +795,15 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
             const float r = ceilf(3.0f * lambda * sigma);
             reject = (floorf(x - r) < minX) || (ceilf(x + r) > maxX) || (floorf(y - r) < minY) || (ceilf(y + r) > maxY);
         }
-        if (reject) {
-            if (lane == 0) ori_count[base + k] = -1;
+        if (reject) {                                                   // (uniform over the workgroup)
+            if (lidx == 0) ori_count[base + k] = -1;
             continue;
         }
         const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // :333-334 Int32 truncation
         const LayerView g = layer_view(layer_ptr(P, frame, o, kp.scale), w, h);
-        for (int c = lane; c < OCOPY * OSTRIDE; c += 64) hist0[c] = 0ull;
-        __builtin_amdgcn_wave_barrier();
+        if (COOP) __syncthreads();                                      // wave 0 is done reading the previous keypoint's bins
+        for (int c = lidx; c < OCOPY * OSTRIDE; c += STRIDE) hist0[c] = 0ull;
+        if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         {   // SIFTOrientation.metal:87-136
             const int x = (int)roundf((float)absoluteX / delta);
             const int y = (int)roundf((float)absoluteY / delta);
@@ -837,10 +844,10 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
                 const float m = wgt * magnitude;
                 atomicAdd(&hist[bin], fix32_product(m, 4294967296.0f));
             };
-            if (interior) { for (int idx = lane; idx < total; idx += 64) sample(std::true_type{}, idx); }
-            else          { for (int idx = lane; idx < total; idx += 64) sample(std::false_type{}, idx); }
+            if (interior) { for (int idx = lidx; idx < total; idx += STRIDE) sample(std::true_type{}, idx); }
+            else          { for (int idx = lidx; idx < total; idx += STRIDE) sample(std::false_type{}, idx); }
         }
-        __builtin_amdgcn_wave_barrier();
+        if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the keypoint
         __threadfence_block();
         const int li = lane < ORI_BINS ? lane : 0;
         unsigned long long hsum = hist0[li];

@@ -825,8 +825,13 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     P.only_octave = only_octave;
     StageRange rg("siftmi orientation + descriptors (getDescriptors)");
     t_begin(c, SIFTMI_T_ORIENT);
-    hipLaunchKernelGGL(orientation_kernel, dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
-                       c->d_ori_angles);
+    const bool coop = (long long)nf * c->ow[0] * c->oh[0] <= small_launch_pixels();   // a frame or two: a whole workgroup per keypoint / descriptor
+    if (coop)
+        hipLaunchKernelGGL(orientation_kernel<true>, dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+                           c->d_ori_angles);
+    else
+        hipLaunchKernelGGL(orientation_kernel<false>, dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+                           c->d_ori_angles);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(expand_descriptors_kernel, dim3(groups), dim3(1024), 0, st, P, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
                        c->d_desc_in, cnt(c, C_DESC), cnt(c, C_ORIENTED));
@@ -834,7 +839,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     t_end(c);
     t_begin(c, SIFTMI_T_DESCRIBE);
     // a frame or two: fewer descriptors than wavefront slots -> one workgroup per descriptor (see descriptor_kernel)
-    if ((long long)nf * c->ow[0] * c->oh[0] <= small_launch_pixels())
+    if (coop)
         hipLaunchKernelGGL(descriptor_kernel<true>, dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                            c->d_desc_f32);
     else
