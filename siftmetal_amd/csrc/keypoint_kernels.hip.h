@@ -882,31 +882,32 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
 }
 
 // Exclusive scan of the orientation counts of one group -> descriptor inputs in keypoint order
-// (SIFTOctave.swift:411-424 expansion).  One 1024-thread workgroup per group.
+// (SIFTOctave.swift:411-424 expansion).  One 1024-thread workgroup per group; the scan is a wave-level shuffle scan plus the 16
+// wave totals (round 3; it was a 10-step Hillis-Steele scan through LDS with 20 barriers: 7 us on a single frame's chain).
 __global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P, const int32_t *__restrict__ kp_count,
                                                                  const int32_t *__restrict__ ori_count, const float *__restrict__ ori_angles,
                                                                  DescInput *__restrict__ desc_in, int32_t *__restrict__ desc_count,
                                                                  int32_t *__restrict__ oriented_count) {
-    __shared__ int part[1024];
-    __shared__ int part2[1024];
+    __shared__ int wsum[16], wori[16];
     const int group = group_index(P, blockIdx.x), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(kp_count[group], P.cap_kp[o]);
     const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
     const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int per = (n + 1023) / 1024;
     const int k0 = threadIdx.x * per, k1 = min(k0 + per, n);
     int sum = 0, nori = 0;
     for (int k = k0; k < k1; k++) { const int c = ori_count[kbase + k]; sum += max(c, 0); nori += (c >= 0); }
-    part[threadIdx.x] = sum; part2[threadIdx.x] = nori;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan
-        int a = 0, b = 0;
-        if ((int)threadIdx.x >= off) { a = part[threadIdx.x - off]; b = part2[threadIdx.x - off]; }
-        __syncthreads();
-        part[threadIdx.x] += a; part2[threadIdx.x] += b;
-        __syncthreads();
+    int incl = sum, incl2 = nori;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64), t2 = __shfl_up(incl2, d, 64);
+        if (lane >= d) { incl += t; incl2 += t2; }
     }
-    int pos = part[threadIdx.x] - sum;
+    if (lane == 63) { wsum[wv] = incl; wori[wv] = incl2; }
+    __syncthreads();
+    int pos = incl - sum, total = 0, total_ori = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) pos += wsum[k]; total += wsum[k]; total_ori += wori[k]; }
     for (int k = k0; k < k1; k++) {
         const int c = ori_count[kbase + k];
         for (int t = 0; t < c; t++, pos++) {
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P,
             }
         }
     }
-    if (threadIdx.x == 1023) { desc_count[group] = part[1023]; oriented_count[group] = part2[1023]; }
+    if (threadIdx.x == 0) { desc_count[group] = total; oriented_count[group] = total_ori; }
 }
 
 // ------------------------------------------------------------------------------------------------
