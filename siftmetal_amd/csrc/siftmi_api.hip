@@ -102,7 +102,7 @@ struct siftmi_ctx {
     unsigned long long *d_keys = nullptr, *d_bucket_keys = nullptr;   // refine's sort keys; the same keys in row-bucket order
     int32_t *d_bucket_src = nullptr, *d_row_count = nullptr, *d_row_start = nullptr;   // keypoint sort (kp_row_* kernels)
     unsigned char *d_act = nullptr;           // DoG activity flags [B][octave][nspo][h][ncell] written by the marching blur
-    long long march_min_blocks = 2000;
+    long long march_min_blocks = 800;
     long long chain_max_tiles = 0;            // blur_chain_kernel for octaves of at most this many tiles (0 = never)
     ZeroJob zero_job{nullptr, 0, nullptr, 0}; // counters to clear at the head of a call, handed to the seed tile kernel (run_dense_detect)
     size_t act_off[MAX_OCT] = {0}, act_frame = 0;
@@ -228,7 +228,7 @@ extern "C" int siftmi_default_config(siftmi_config *cfg, int32_t width, int32_t 
     cfg->max_batch = 1;
     cfg->use_hip_graph = 1;
     cfg->count_raw_extrema = 0;
-    cfg->blur_march_min_blocks = 2000;
+    cfg->blur_march_min_blocks = 800;
     return SIFTMI_OK;
 }
 
@@ -292,7 +292,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     c->cfg = *cfg;
     c->device = hip_device;
     c->n_oct = cfg->n_octaves; c->nspo = cfg->nspo; c->B = cfg->max_batch;
-    c->march_min_blocks = cfg->blur_march_min_blocks > 0 ? cfg->blur_march_min_blocks : 2000;
+    c->march_min_blocks = cfg->blur_march_min_blocks > 0 ? cfg->blur_march_min_blocks : 800;
     c->chain_max_tiles = cfg->blur_chain_max_tiles > 0 ? cfg->blur_chain_max_tiles : (cfg->blur_chain_max_tiles == 0 ? 256 : 0);
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_launches, 0, sizeof(c->t_launches));
     memset(c->t_blur_ms, 0, sizeof(c->t_blur_ms)); memset(c->t_blur_launches, 0, sizeof(c->t_blur_launches));
@@ -477,7 +477,9 @@ static int march_chunk_rows(int h) {
     return h >= 1600 ? 256 : 160;
 }
 
-// the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 2000)
+// the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 800 = about one
+// round of resident workgroups; 2000 until round 3: 3 ... 6 frames of 1920x1080 per step run 4-11 % faster with the ring kernel on
+// octave 0, tools/batch_size_sweep.py with MARCH_MIN)
 static bool uses_march(const siftmi_ctx *c, int w, int h, int nf) {
     using Gm = RingGeom<1>;
     const int chr = march_chunk_rows(h);
