@@ -10,7 +10,8 @@ from tests.synth import blob_frame
 L = _capi.load()
 frames = np.stack([blob_frame(1920, 1080, i) for i in range(8)])
 for F in [int(x) for x in os.environ.get("SWEEP_F", "1,2,3,4,6,8,16,32,64").split(",")]:
-    eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=F, **({"blur_march_min_blocks": int(os.environ["MARCH_MIN"])} if os.environ.get("MARCH_MIN") else {}))
+    eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=F, **({"blur_march_min_blocks": int(os.environ["MARCH_MIN"])} if os.environ.get("MARCH_MIN") else {}),
+                    **({"blur_chain_max_tiles": int(os.environ["CHAIN_MAX"])} if os.environ.get("CHAIN_MAX") else {}))
     d = smstream.DeviceFrames(np.concatenate([frames] * ((F + 7) // 8))[:F])
     out = []
     for pipe in (1, 2):
