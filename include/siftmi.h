@@ -84,8 +84,8 @@ typedef struct siftmi_config {
                                            dog_threshold); same candidates, keypoints and descriptors, but the raw_extrema
                                            statistic then counts tested rows only (siftmi_stats.raw_extrema_exact = 0).
                                            1 = scan every row, exact raw_extrema. */
-    int32_t blur_march_min_blocks;      /* launches with at least this many 128 x 128 workgroups use the marching blur
-                                           (default 800; 1 = always, for tests) */
+    int32_t blur_march_min_blocks;      /* layer launches of at least this many workgroups (128-column strips x 160- or 256-row
+                                           chunks x frames) use the marching ring blur (default 800; 1 = always, for tests) */
     int32_t blur_chain_max_tiles;       /* an octave of at most this many 64 x 64 tiles (frames x tiles) gets its Gaussian layers 1-3 and
                                            4-5 from ONE launch each (single frames: fewer dependent launches per call).  0 = default
                                            (256: the 960x540 and 480x270 octaves of one 1920x1080 frame), -1 = off.  Default schedule only (nspo = 3,
