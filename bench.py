@@ -121,7 +121,7 @@ def self_launch(args):
     """--gpus N > 1 without a torchrun environment: spawn the ranks (no GPU call has happened in this process)."""
     import torch
     n_dev = torch.cuda.device_count()                      # does not initialise the GPU runtime
-    if n_dev < args.gpus:
+    if n_dev < (1 if args.share_gpu else args.gpus):
         print("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, n_dev), file=sys.stderr)
         return 3
     s = socket.socket()
@@ -165,6 +165,10 @@ def main():
                     "so that every kernel runs alone (per-kernel traces: tools/profile_round.sh)")
     ap.add_argument("--pipeline", type=int, default=2, choices=(1, 2),
                     help="steps in flight: 2 alternates consecutive steps between two contexts (two pyramids) on two streams")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: let the N ranks share the visible device(s) (rank r on device r mod n_devices).  Real RCCL refuses two ranks "
+                         "on one GPU; with SIFTMI_RCCL_LIB=tests/c/libfake_rccl.so the exchange runs over shared memory, which exercises "
+                         "self-launch -> unique-id broadcast -> siftmi_exchange_* with N ranks -> one JSON line on a 1-GPU box")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip single_frame / host_io / dense")
@@ -189,7 +193,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    if torch.cuda.device_count() == 1 and local_rank > 0:
+    if args.share_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif torch.cuda.device_count() == 1 and local_rank > 0:
         local_rank = 0                                      # a launcher that shows every rank its own GPU only (HIP_VISIBLE_DEVICES per rank)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: local rank %d but only %d HIP device(s) visible" % (local_rank, torch.cuda.device_count()))
@@ -224,7 +230,10 @@ def main():
         tune["graph_fork"] = -1
     eng = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
     uid = None
+    transport = None
     if use_dist:
+        origin = _capi.load().siftmi_exchange_transport().decode("utf-8", "replace")
+        transport = ("test transport %s (shared memory between ranks that share a GPU; NOT RCCL)" % origin) if "fake_rccl" in origin else "librccl: %s" % origin
         box = [smstream.Exchange.make_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
@@ -299,6 +308,8 @@ def main():
                                      "stages run under the previous step's VALU-bound keypoint stages; every step is computed in full, the "
                                      "timed region ends with a device synchronisation") if args.pipeline > 1 else None,
                       "rccl_ranks": world if use_dist else 0,
+                      "ranks_share_one_gpu": bool(args.share_gpu),
+                      "all_gather_transport": transport,
                       "ms_per_step_by_rank": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
                       "all_gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4),
                       "all_gather_bytes_received_per_rank_per_step": gather_bytes,

@@ -320,6 +320,8 @@ typedef struct siftmi_gathered {
     int64_t kp_records, desc_records;   /* records sent per rank                                                       */
     int32_t resolved, reserved;
 } siftmi_gathered;
+/* The pointers and strides of a siftmi_gathered stay valid until the second siftmi_exchange_gather / _finish call after the
+   one that produced them (two buffer sets; a set that has to grow is replaced, the old block is kept until then). */
 
 /* An exchange belongs to one stream: destroy it before the stream.  Its calls marked "collective" must be made by every
    rank in the same order (they enqueue RCCL collectives).
@@ -343,6 +345,9 @@ int  siftmi_exchange_finish(siftmi_exchange *x, int64_t *regathered_steps, int64
 int  siftmi_exchange_set_headroom(siftmi_exchange *x, int32_t headroom_percent, int64_t quantum);
 /* accumulated GPU time of the gathers (side-stream hipEvents) and their number since creation; bytes received per gather */
 int  siftmi_exchange_stats(siftmi_exchange *x, double *ms, int64_t *gathers, int64_t *bytes_last);
+/* which library carries the collectives: the path / soname the seven ncclXxx entry points were resolved from (SIFTMI_RCCL_LIB
+   if set, else an RCCL already mapped into the process, else librccl.so[.1]); "" if none could be loaded.  Loads it. */
+const char *siftmi_exchange_transport(void);
 
 /* The sizing rule of the exchange alone (host arithmetic, no GPU, no RCCL): what siftmi_exchange_gather uses, exposed so
    that the rule can be driven over any transport (tests/test_dist_gloo.py drives it over gloo on CPU). */

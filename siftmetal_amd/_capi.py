@@ -24,7 +24,7 @@ EXPORTS = [
     "siftmi_stream_submit_device", "siftmi_stream_submit_host", "siftmi_stream_wait_upload", "siftmi_stream_wait_consumed",
     "siftmi_stream_result_device", "siftmi_stream_result_host", "siftmi_stream_synchronize",
     "siftmi_exchange_unique_id", "siftmi_exchange_create", "siftmi_exchange_destroy", "siftmi_exchange_gather",
-    "siftmi_exchange_result", "siftmi_exchange_finish", "siftmi_exchange_stats", "siftmi_exchange_set_headroom",
+    "siftmi_exchange_result", "siftmi_exchange_finish", "siftmi_exchange_stats", "siftmi_exchange_set_headroom", "siftmi_exchange_transport",
     "siftmi_gather_plan_init", "siftmi_gather_plan_resolve",
 ]
 NO_STREAM = C.c_void_p(-1).value          # SIFTMI_NO_STREAM
@@ -171,6 +171,8 @@ def load():
     L.siftmi_exchange_finish.argtypes = [vp, i64p, i64p]
     L.siftmi_exchange_set_headroom.argtypes = [vp, C.c_int32, C.c_int64]
     L.siftmi_exchange_stats.argtypes = [vp, C.POINTER(C.c_double), i64p, i64p]
+    L.siftmi_exchange_transport.argtypes = []
+    L.siftmi_exchange_transport.restype = C.c_char_p
     L.siftmi_gather_plan_init.argtypes = [C.POINTER(GatherPlan), C.c_int64, C.c_int64]
     L.siftmi_gather_plan_resolve.argtypes = [C.POINTER(GatherPlan), vp, C.c_int, C.c_int64, C.c_int64]
     _lib = L

@@ -58,6 +58,8 @@ static int rccl_ready() {
 
 static_assert(SIFTMI_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
 
+extern "C" const char *siftmi_exchange_transport(void) { return rccl().ok ? rccl().origin.c_str() : ""; }
+
 // ------------------------------------------------------------------------------------------------
 // the sizing rule (host arithmetic only)
 extern "C" int siftmi_gather_plan_init(siftmi_gather_plan *p, int64_t kp_capacity, int64_t desc_capacity) {
@@ -99,6 +101,9 @@ extern "C" int siftmi_gather_plan_resolve(siftmi_gather_plan *p, const int32_t *
 struct GatherSet {
     uint8_t *kp = nullptr, *desc = nullptr;
     size_t kp_bytes = 0, desc_bytes = 0;          // allocated
+    // a block that had to grow is kept until this set is recycled the next time: a consumer stream handed the old pointers by
+    // siftmi_exchange_result(consumer_stream, wait_host = 0) may still be reading them (the validity window siftmi.h states)
+    std::vector<void *> retired;
     int32_t *counts = nullptr, *totals = nullptr; // device [world][2][F][n_oct], [world][4]
     int32_t *h_totals = nullptr;                  // pinned [world][4]
     hipEvent_t ev_done = nullptr, ev_totals = nullptr, t0 = nullptr, t1 = nullptr;
@@ -136,6 +141,7 @@ extern "C" void siftmi_exchange_destroy(siftmi_exchange *x) {
     for (auto &g : x->g) {
         void *ptrs[] = {g.kp, g.desc, g.counts, g.totals};
         for (void *p : ptrs) if (p) (void)hipFree(p);
+        for (void *p : g.retired) (void)hipFree(p);
         if (g.h_totals) (void)hipHostFree(g.h_totals);
         hipEvent_t evs[] = {g.ev_done, g.ev_totals, g.t0, g.t1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -185,23 +191,38 @@ extern "C" int siftmi_exchange_create(siftmi_stream *s, const void *unique_id, i
     return SIFTMI_OK;
 }
 
+// A gathered set whose buffers are too small gets NEW blocks (1.5 x the need, so a growing scene does not reallocate every
+// step); the old ones are not freed here -- no hipFree (a device-wide synchronisation) between collectives that the other ranks
+// have already enqueued, and a consumer stream may still read them -- but when the set is next recycled (recycle_gather_set).
 static int grow_gather(siftmi_exchange *x, GatherSet &g, int64_t send_kp, int64_t send_desc) {
     const size_t need_kp = (size_t)x->world * (size_t)send_kp * sizeof(KeypointRec);
     const size_t need_desc = (size_t)x->world * (size_t)send_desc * sizeof(DescriptorRec);
     if (need_kp > g.kp_bytes) {
-        HIP_TRY(hipStreamSynchronize(x->gstream));
-        if (g.kp) (void)hipFree(g.kp);
-        g.kp = nullptr; g.kp_bytes = 0;
-        HIP_TRY(hipMalloc((void **)&g.kp, need_kp + need_kp / 4));
-        g.kp_bytes = need_kp + need_kp / 4;
+        uint8_t *fresh = nullptr;
+        const size_t bytes = need_kp + need_kp / 2;
+        hipError_t e = hipMalloc((void **)&fresh, bytes);
+        if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? SIFTMI_E_NOMEM : SIFTMI_E_HIP, "gathered keypoints (%zu bytes): %s", bytes, hipGetErrorString(e));
+        if (g.kp) g.retired.push_back(g.kp);
+        g.kp = fresh; g.kp_bytes = bytes;
     }
     if (need_desc > g.desc_bytes) {
-        HIP_TRY(hipStreamSynchronize(x->gstream));
-        if (g.desc) (void)hipFree(g.desc);
-        g.desc = nullptr; g.desc_bytes = 0;
-        HIP_TRY(hipMalloc((void **)&g.desc, need_desc + need_desc / 4));
-        g.desc_bytes = need_desc + need_desc / 4;
+        uint8_t *fresh = nullptr;
+        const size_t bytes = need_desc + need_desc / 2;
+        hipError_t e = hipMalloc((void **)&fresh, bytes);
+        if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? SIFTMI_E_NOMEM : SIFTMI_E_HIP, "gathered descriptors (%zu bytes): %s", bytes, hipGetErrorString(e));
+        if (g.desc) g.retired.push_back(g.desc);
+        g.desc = fresh; g.desc_bytes = bytes;
     }
+    return SIFTMI_OK;
+}
+
+// the set is about to hold a new step: blocks it outgrew two gathers ago can go (every gather that wrote them has finished --
+// ev_done of the set -- and the window in which a consumer may hold their addresses is over)
+static int recycle_gather_set(GatherSet &g) {
+    if (g.retired.empty()) return SIFTMI_OK;
+    if (g.step >= 0) HIP_TRY(hipEventSynchronize(g.ev_done));
+    for (void *p : g.retired) (void)hipFree(p);
+    g.retired.clear();
     return SIFTMI_OK;
 }
 
@@ -211,10 +232,14 @@ static int payload_gathers(siftmi_exchange *x, StreamResultSet &rs, GatherSet &g
     if (rc) return rc;
     const size_t n_counts = 2 * (size_t)x->s->F * x->s->n_oct;
     RCCL_TRY(rccl().GroupStart());
-    if (with_counts) RCCL_TRY(rccl().AllGather(rs.d_counts, g.counts, n_counts, ncclInt32, x->comm, x->gstream));
-    RCCL_TRY(rccl().AllGather(rs.d_kp, g.kp, (size_t)send_kp * sizeof(KeypointRec), ncclUint8, x->comm, x->gstream));
-    RCCL_TRY(rccl().AllGather(rs.d_desc, g.desc, (size_t)send_desc * sizeof(DescriptorRec), ncclUint8, x->comm, x->gstream));
-    RCCL_TRY(rccl().GroupEnd());
+    ncclResult_t r = ncclSuccess;                             // a failing member must not leave the group open
+    const char *what = "ncclAllGather(counts)";
+    if (with_counts) r = rccl().AllGather(rs.d_counts, g.counts, n_counts, ncclInt32, x->comm, x->gstream);
+    if (r == ncclSuccess) { what = "ncclAllGather(keypoints)"; r = rccl().AllGather(rs.d_kp, g.kp, (size_t)send_kp * sizeof(KeypointRec), ncclUint8, x->comm, x->gstream); }
+    if (r == ncclSuccess) { what = "ncclAllGather(descriptors)"; r = rccl().AllGather(rs.d_desc, g.desc, (size_t)send_desc * sizeof(DescriptorRec), ncclUint8, x->comm, x->gstream); }
+    const ncclResult_t r_end = rccl().GroupEnd();
+    if (r != ncclSuccess) return set_error(SIFTMI_E_HIP, "%s failed: %s", what, rccl().GetErrorString(r));
+    if (r_end != ncclSuccess) return set_error(SIFTMI_E_HIP, "ncclGroupEnd failed: %s", rccl().GetErrorString(r_end));
     g.sent_kp = send_kp; g.sent_desc = send_desc;
     x->bytes_last = (int64_t)x->world * (int64_t)(n_counts * 4 + (size_t)send_kp * sizeof(KeypointRec) + (size_t)send_desc * sizeof(DescriptorRec) + 16);
     HIP_TRY(hipEventRecord(g.ev_done, x->gstream));
@@ -271,11 +296,13 @@ extern "C" int siftmi_exchange_gather(siftmi_exchange *x, int synchronous) {
     int rc;
     // the set being recycled held the gather before the previous one: long finished; it was resolved when `prev` was issued
     collect_time(x, g);
+    if ((rc = recycle_gather_set(g))) return rc;
     HIP_TRY(hipStreamWaitEvent(x->gstream, rs.ev_ready, 0));
     HIP_TRY(hipEventRecord(g.t0, x->gstream));
     RCCL_TRY(rccl().AllGather(rs.d_totals, g.totals, 4, ncclInt32, x->comm, x->gstream));
     HIP_TRY(hipMemcpyAsync(g.h_totals, g.totals, (size_t)x->world * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, x->gstream));
     HIP_TRY(hipEventRecord(g.ev_totals, x->gstream));
+    // from here on the set holds this step (its totals collective is enqueued on every rank)
     g.step = s->step_no; g.resolved = false; g.complete = false; g.needs_regather = false;
     // the previous step's totals arrived while this step's kernels ran: check it, re-gather it if it was cut short, re-size
     if ((rc = resolve_gather(x, prev))) return rc;

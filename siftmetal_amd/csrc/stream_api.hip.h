@@ -210,8 +210,10 @@ static int start_host_copy(siftmi_stream *s, StreamResultSet &rs) {
     return SIFTMI_OK;
 }
 
+// slot >= 0: the frames sit in staging buffer `slot` (submit_host); its bookkeeping is committed with the launch, before
+// anything that can still fail, so that the next upload into the slot always waits for this step
 static int submit_step(siftmi_stream *s, const void *d_pixels, size_t row_stride, size_t frame_stride, void *producer_stream,
-                       hipEvent_t uploaded, int64_t *step) {
+                       hipEvent_t uploaded, int64_t *step, int slot = -1) {
     const int64_t k = s->step_no + 1;
     const int ci = (int)(k % s->n_ctx);
     StreamResultSet &rs = s->sets[(size_t)(k % s->n_sets)];
@@ -227,16 +229,23 @@ static int submit_step(siftmi_stream *s, const void *d_pixels, size_t row_stride
     const int rc = siftmi_detect_describe_batch_device(s->ctx[ci], s->F, d_pixels, s->scfg.format, row_stride, frame_stride, (siftmi_keypoint *)rs.d_kp,
                                                        s->kp_cap, (siftmi_descriptor *)rs.d_desc, s->desc_cap, rs.d_counts, rs.d_totals, ls);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(rs.ev_ready, ls));
-    rs.ready_rec = true; rs.gather_rec = false; rs.d2h_rec = false;
+    // the step is launched: commit its bookkeeping first (events recorded on a healthy stream do not fail; if one does, the
+    // state still says "this set / slot belongs to step k")
     rs.step = k; rs.host_done = false; rs.spec_kp = rs.spec_desc = 0;
+    rs.gather_rec = false; rs.d2h_rec = false;
     s->step_no = k;
+    if (step) *step = k;
+    if (slot >= 0) {
+        s->slot_step[(size_t)slot] = k;
+        if (hipEventRecord(s->ev_slot_read[(size_t)slot], ls) == hipSuccess) s->slot_read_rec[(size_t)slot] = 1;
+    }
+    HIP_TRY(hipEventRecord(rs.ev_ready, ls));
+    rs.ready_rec = true;
     if (s->host_reader) {
         s->host_reader = false;
         const int rc2 = start_host_copy(s, rs);
         if (rc2) return rc2;
     }
-    if (step) *step = k;
     return SIFTMI_OK;
 }
 
@@ -264,7 +273,15 @@ extern "C" int siftmi_stream_submit_host(siftmi_stream *s, const void *pixels, s
             hipError_t e = hipMalloc((void **)&s->staging[(size_t)i], (size_t)s->F * s->frame_bytes);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_uploaded[(size_t)i], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_slot_read[(size_t)i], hipEventDisableTiming);
-            if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? SIFTMI_E_NOMEM : SIFTMI_E_HIP, "staging buffers: %s", hipGetErrorString(e));
+            if (e != hipSuccess) {
+                // leave no half-built state behind: a later call starts the allocation over instead of using null buffers
+                for (unsigned char *p : s->staging) if (p) (void)hipFree(p);
+                for (hipEvent_t ev : s->ev_uploaded) if (ev) (void)hipEventDestroy(ev);
+                for (hipEvent_t ev : s->ev_slot_read) if (ev) (void)hipEventDestroy(ev);
+                s->staging.clear(); s->ev_uploaded.clear(); s->ev_slot_read.clear(); s->slot_step.clear(); s->slot_read_rec.clear();
+                (void)hipGetLastError();
+                return set_error(e == hipErrorOutOfMemory ? SIFTMI_E_NOMEM : SIFTMI_E_HIP, "staging buffers: %s", hipGetErrorString(e));
+            }
         }
     }
     const int64_t k = s->step_no + 1;
@@ -279,12 +296,7 @@ extern "C" int siftmi_stream_submit_host(siftmi_stream *s, const void *pixels, s
                                      s->row_bytes, (size_t)s->ctx[0]->cfg.height, hipMemcpyHostToDevice, s->copy_stream));
     }
     HIP_TRY(hipEventRecord(s->ev_uploaded[slot], s->copy_stream));
-    const int rc = submit_step(s, dst, s->row_bytes, s->frame_bytes, SIFTMI_NO_STREAM, s->ev_uploaded[slot], step);
-    if (rc) return rc;
-    s->slot_step[slot] = k;
-    HIP_TRY(hipEventRecord(s->ev_slot_read[slot], s->launch[k % s->n_ctx]));
-    s->slot_read_rec[slot] = 1;
-    return SIFTMI_OK;
+    return submit_step(s, dst, s->row_bytes, s->frame_bytes, SIFTMI_NO_STREAM, s->ev_uploaded[slot], step, (int)slot);
 }
 
 extern "C" int siftmi_stream_wait_upload(siftmi_stream *s, int64_t step) {

@@ -15,6 +15,12 @@ from . import _capi
 KP_BYTES, DESC_BYTES = 44, 136
 
 
+def shard_frames(n_frames, world_size, rank):
+    """Frame-per-GPU sharding of a frame stream: frame i -> rank i mod world_size; this rank's frame indices.
+    Frames are independent units (the reference keeps no cross-frame state), so nothing else is partitioned."""
+    return list(range(rank, n_frames, world_size))
+
+
 def _torch_stream_handle(device):
     """hipStream_t of torch's current stream on `device` (0 = the legacy default stream) -- torch is only touched when the
     caller hands in torch tensors."""

@@ -1,4 +1,10 @@
-"""Frame-per-GPU sharding and the descriptor all-gather (the only exchange step of the path).
+"""TEST-ONLY mirror of the result exchange's protocol over torch.distributed (gloo), for the CPU tests (tests/test_dist_gloo.py).
+
+The product exchange is siftmi_exchange_* inside libsiftmi.so (siftmetal_amd/csrc/exchange_api.hip.h; multi-rank runs of it:
+tests/test_exchange_ranks.py).  What this module adds is a way to drive the library's own SIZING RULE (siftmi_gather_plan_*, host
+arithmetic exported by the C ABI) with world size 2 where there is no GPU.  Nothing in siftmetal_amd/ imports it.
+
+Frame-per-GPU sharding and the descriptor all-gather (the only exchange step of the path).
 
 Frames are independent units (the reference keeps no cross-frame state: SIFT.swift holds only
 scratch), so a stream of frames shards with no data-path collective; after a batch every rank
@@ -29,9 +35,7 @@ KP_BYTES, DESC_BYTES = 44, 136
 TOTALS = 4                      # {n_keypoints, n_descriptors, overflow_flags, 0} (include/siftmi.h, d_totals)
 
 
-def shard_frames(n_frames: int, world_size: int, rank: int) -> List[int]:
-    """frame i -> rank i mod world_size; returns this rank's frame indices."""
-    return list(range(rank, n_frames, world_size))
+from siftmetal_amd.stream import shard_frames  # noqa: E402,F401  (the sharding rule itself is product code)
 
 
 def _totals_row(totals: torch.Tensor) -> torch.Tensor:
@@ -81,7 +85,7 @@ class ResultExchange:
     siftmi_exchange_gather (include/siftmi.h) over torch.distributed, sized by siftmi_gather_plan_*."""
 
     def __init__(self, kp_capacity: int, desc_capacity: int, group=None, headroom: float = 1.25, quantum: int = 1024):
-        from . import _capi
+        from siftmetal_amd import _capi
         self._capi = _capi
         self.L = _capi.load()
         self.plan = _capi.GatherPlan()

@@ -1,5 +1,5 @@
 """world_size-2 gloo test (CPU) of the N>1 path: frame sharding + count exchange + padded all-gather
-of packed keypoint/descriptor buffers (siftmetal_amd/dist.py).  The per-rank buffers are produced by
+of packed keypoint/descriptor buffers (tests/gloo_exchange.py, a test-only mirror of the protocol; the C exchange itself runs multi-rank in tests/test_exchange_ranks.py).  The per-rank buffers are produced by
 the CPU oracle here (checker role) because the product path needs a GPU."""
 import os
 import socket
@@ -22,7 +22,8 @@ def _free_port():
 def _rank_results(rank, world, n_frames):
     """Packed siftmi-format records for this rank's frames, computed with the oracle."""
     from oracle import pyoracle
-    from siftmetal_amd import _capi, dist as smdist
+    from siftmetal_amd import _capi
+    from tests import gloo_exchange as smdist
     from tests.synth import blob_frame
     mine = smdist.shard_frames(n_frames, world, rank)
     kps, descs = [], []
@@ -49,7 +50,8 @@ def _worker(rank, world, port, n_frames, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from siftmetal_amd import _capi, dist as smdist
+        from siftmetal_amd import _capi
+        from tests import gloo_exchange as smdist
         mine, kp, ds, counts = _rank_results(rank, world, n_frames)
         cap_kp, cap_ds = 4096, 4096
         kp_b = torch.zeros(cap_kp * smdist.KP_BYTES, dtype=torch.uint8)
@@ -71,7 +73,7 @@ def _worker(rank, world, port, n_frames, q):
 
 
 def test_shard_frames():
-    from siftmetal_amd import dist as smdist
+    from tests import gloo_exchange as smdist
     assert smdist.shard_frames(5, 2, 0) == [0, 2, 4] and smdist.shard_frames(5, 2, 1) == [1, 3]
     got = sorted(sum((smdist.shard_frames(512, 8, r) for r in range(8)), []))
     assert got == list(range(512)) and all(len(smdist.shard_frames(512, 8, r)) == 64 for r in range(8))
@@ -111,7 +113,7 @@ def _exchange_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from siftmetal_amd import dist as smdist
+        from tests import gloo_exchange as smdist
         cap = 4096
         ex = smdist.ResultExchange(cap, cap, headroom=1.25, quantum=64)
         rng = np.random.default_rng(100 + rank)
