@@ -46,8 +46,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 W, H, N_OCT, NSPO = 1920, 1080, 4, 3
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-HBM_COPY_GBS = 6290.0          # same guide: measured float4 copy rate
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (the copy rate is MEASURED in the run: roofline.peak_measured)
+MFMA_I8_DENSE_PEAK_TFLOPS = 5000.0      # same guide: int8 dense = 2x bf16 (2.5 PFLOP/s)
 
 
 def log(*a):
@@ -56,9 +56,47 @@ def log(*a):
 
 
 def make_frames(n, distinct):
+    """n synthetic frames, `distinct` of them different (default: all) -- generated on a few host threads (0.25 s per frame)."""
+    from concurrent.futures import ThreadPoolExecutor
     from tests.synth import blob_frame
-    base = [blob_frame(W, H, i) for i in range(min(n, distinct))]
-    return np.stack([base[i % len(base)] for i in range(n)])
+    k = min(n, distinct)
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        base = list(ex.map(lambda i: blob_frame(W, H, i), range(k)))
+    return np.stack([base[i % k] for i in range(n)])
+
+
+def match_extra(eng, local_rank):
+    """SURVEY.md 8f row f1 in the driver's line: siftmi_match_descriptors (SIFTDescriptor.match, SIFT/SIFTDescriptor.swift:298-361;
+    int8 MFMA, exact int32 accumulation) on descriptors resident in HBM, whole call including the 12 B/source result copy."""
+    import ctypes as C
+    from siftmetal_amd import _capi, stream as smstream
+    import siftmetal_amd as sm
+    out = {}
+    rng = np.random.default_rng(0)
+    for ns, nt in ((20000, 20000), (100000, 100000)):
+        tgt = np.zeros(nt, sm.descriptor_dtype)
+        tgt["features"] = np.clip(np.abs(rng.normal(0, 40, (nt, 128))), 0, 255)
+        src = np.zeros(ns, sm.descriptor_dtype)
+        src["features"] = np.clip(tgt["features"][rng.integers(0, nt, ns)].astype(np.int32) + rng.integers(-12, 13, (ns, 128)), 0, 255)
+        d_src, d_tgt = smstream.DeviceFrames(src.view(np.uint8), local_rank), smstream.DeviceFrames(tgt.view(np.uint8), local_rank)
+        res, n = C.c_void_p(), C.c_int64()
+
+        def call():
+            _capi.check(eng.L.siftmi_match_descriptors(eng.h, d_src.ptr, ns, d_tgt.ptr, nt, 1, 1.176, 0.6, C.byref(res), C.byref(n)))
+
+        call()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        dt = (time.perf_counter() - t0) / reps
+        tf = ns * nt * 256 / dt / 1e12
+        out["%dk_x_%dk" % (ns // 1000, nt // 1000)] = {"ms_per_call": round(dt * 1e3, 4), "Gpairs_per_s": round(ns * nt / dt / 1e9, 1), "matches": int(n.value),
+                                                      "int8_TFLOPs": round(tf, 1), "frac_of_int8_mfma_peak": round(tf / MFMA_I8_DENSE_PEAK_TFLOPS, 4)}
+        d_src.close(); d_tgt.close()
+    out["workload"] = ("siftmi_match_descriptors (brute force + ratio test, SIFTDescriptor.match), descriptors resident in HBM, whole call incl. the host copy of "
+                       "the match records; bound = int8 MFMA, peak %.0f TFLOP/s dense" % MFMA_I8_DENSE_PEAK_TFLOPS)
+    return out
 
 
 def make_dense_frames(n):
@@ -159,7 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SIFTMI_BATCH", "64")), help="frames processed in lock-step per launch")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (cycled to fill the batch)")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames (cycled to fill the batch when fewer than --frames)")
     ap.add_argument("--march-min-blocks", type=int, default=0, help="siftmi_config.blur_march_min_blocks (0 = library default)")
     ap.add_argument("--serial-graph", action="store_true", help="siftmi_config.graph_fork = -1: the captured launch sequence stays one chain, "
                     "so that every kernel runs alone (per-kernel traces: tools/profile_round.sh)")
@@ -299,9 +337,10 @@ def main():
     out = {"metric": "Mpixels/sec detect+describe (1920x1080, 4 octaves)", "value": round(value, 2), "unit": "Mpixels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%d x 1920x1080 BGRA8 frames per GPU per step (BASELINE configs[2]/[3]), %d octaves x %d scales/octave, "
-                                  "detect+describe, frames and results resident in HBM%s" %
-                                  (F, N_OCT, NSPO, ", RCCL all-gather of descriptors" if world > 1 else ""),
+           "config": {"workload": "%d x 1920x1080 BGRA8 frames per GPU per step (BASELINE configs[2]/[3]; %d distinct synthetic frames), %d octaves x %d scales/octave, "
+                                  "detect+describe, frames and results resident in HBM%s.  `value` EXCLUDES PCIe; the metric as SURVEY.md 8d words it (H2D of the "
+                                  "frames and D2H of keypoints + descriptors included) is host_io_stream_Mpixels_per_s in this line" %
+                                  (F, min(F, args.distinct), N_OCT, NSPO, ", RCCL all-gather of descriptors" if world > 1 else ""),
                       "frames_per_gpu": F, "lockstep_batch": eng.max_batch, "parallelism": "frame-per-GPU x%d" % world,
                       "steps_in_flight": args.pipeline,
                       "pipelining": ("consecutive steps alternate between two contexts (two pyramids, two streams): a step's HBM-bound dense "
@@ -374,15 +413,44 @@ def main():
                 traffic = int(ratio * total_bytes / max(blur_n, 1))
                 traffic_src = ("profiles/%s: PMC bytes / algorithmic bytes = %.3f averaged over the five octave-0 layer launches of the "
                                "pipeline, scaled to the average launch" % (prof[-1], ratio))
+        # the ceilings, measured on THIS device in THIS run: a plain float4 copy of one octave-0 layer launch's bytes
+        # inside the same pyramid memory, and the ring kernel itself with its arithmetic compiled out (same loads, LDS staging,
+        # barriers and stores).  Both overwrite the pyramid; every later measurement recomputes it.
+        launch_bytes = eng.blur_algorithmic_bytes(0) * eng.max_batch
+        copy_ms, copy_moved = eng.time_copy(launch_bytes // 2, 10)
+        copy_gbs = copy_moved / (copy_ms * 1e-3) / 1e9
+        mem_only = {}
+        for layer in range(1, NSPO + 3):
+            try:
+                ms = eng.time_blur_memory(0, layer, 10)
+                mem_only["o0_l%d_taps%d" % (layer, len(eng.weights(layer)))] = round(launch_bytes / (ms * 1e-3) / 1e9, 1)
+            except sm.SiftmiError:
+                pass
+        log("measured float4 copy: %.0f GB/s (%.2f GB per launch); ring kernel without arithmetic, octave 0 by layer: %s" % (copy_gbs, copy_moved / 1e9, mem_only))
+        # the seed launch (luma + 2x bilinear + blur, one kernel): 4 B read per input pixel, 16 B (four octave-0 floats) written
+        seed_ms, seed_n = tm["seed"]
+        seed_bytes = 20 * W * H * eng.max_batch
+        seed_gbs = seed_bytes / (seed_ms / max(seed_n, 1) * 1e-3) / 1e9 if seed_ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": "blur_ring_kernel<R> (large launches) / blur2_kernel<R> (small octaves): one Gaussian layer, fused X+Y",
                            "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "traffic_source": traffic_src, "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBS, 4),
+                           "traffic_source": traffic_src,
+                           "peak_measured": round(copy_gbs, 1), "frac_of_measured": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None,
+                           "peak_measured_how": "siftmi_time_copy: one-pass float4 streaming copy of %.2f GB (read + written) inside this context's pyramid memory, the faster "
+                                                "of plain and non-temporal loads / stores, mean of 10 launches after a warm-up, hipEvents, this device, this run" % (copy_moved / 1e9),
+                           "memory_only_GBps_by_layer": mem_only,
+                           "memory_only_how": "siftmi_time_blur_memory: the layer's ring kernel with both passes' arithmetic compiled out (same loads, LDS staging, barriers, stores)",
+                           "seed": {"kernel": "blur_ring_kernel<5, ..., SEEDF> (luma + 2x bilinear + seed blur, one launch)", "launches": seed_n,
+                                    "algorithmic_bytes_per_launch": seed_bytes, "avg_launch_us": round(seed_ms / max(seed_n, 1) * 1e3, 2),
+                                    "achieved": round(seed_gbs, 1), "frac": round(seed_gbs / HBM_PEAK_GBS, 4),
+                                    "frac_of_measured": round(seed_gbs / copy_gbs, 4) if copy_gbs > 0 else None},
                            "launches": blur_n, "avg_launch_ms": round(blur_ms / max(blur_n, 1), 5),
                            "algorithmic_bytes_per_launch_avg": int(total_bytes / max(blur_n, 1)),
                            "octave0_GBps_by_layer": per_layer, "by_launch_shape": shapes, "stage_ms_per_step": stage_ms,
                            "measured_in": "second identical pass of K steps on one context, one step at a time, hipEvents around every launch on the launch stream"}
     if rank == 0 and not args.no_extras:
+        out["extras"] = {"match": match_extra(eng, local_rank)}
+        log("matcher:", out["extras"]["match"])
         # BASELINE configs[1]: ONE 1920x1080 frame per call (lock-step batch 1, hipGraph replay), frame in HBM
         e1 = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=1)
         r1 = smstream.FrameStream(e1, 1, device=dev)

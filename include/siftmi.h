@@ -43,7 +43,11 @@ typedef enum siftmi_status {
 } siftmi_status;
 
 /* Pixel formats.  The reference accepts only a .bgra8Unorm texture
-   (Metal Compute/ConvertSRGBToGrayscaleKernel.swift:34); GRAY8/GRAYF32 skip the luma step. */
+   (Metal Compute/ConvertSRGBToGrayscaleKernel.swift:34); GRAY8/GRAYF32 skip the luma step.
+   SIFTMI_FMT_GRAYF32 pixels are the luma itself and must lie in [0, 1], the range a unorm texture delivers: thresholds are absolute
+   and the orientation / descriptor histograms are accumulated in 2^-32 fixed point, which saturates for gradients of an
+   unnormalised (0 ... 255, HDR) image.  A frame with a value outside [0, 1] (or a NaN) is reported: SIFTMI_E_BADARG from the
+   host-facing entry points, overflow_flags bit 5 on the device path; its results are not to be used. */
 typedef enum siftmi_format {
     SIFTMI_FMT_BGRA8   = 0,
     SIFTMI_FMT_GRAY8   = 1,
@@ -185,7 +189,8 @@ int siftmi_detect_describe_batch(siftmi_ctx *ctx, int32_t n_frames, const void *
    [2][n_frames][n_octaves] int32 (keypoints, then descriptors); d_totals receives FOUR int32:
    {n_kp, n_desc, overflow_flags, 0}.  overflow_flags != 0 means a list was truncated (bit 0 max_extrema, 1 max_keypoints,
    2 max_descriptors, 3 kp_capacity, 4 desc_capacity) -- the condition the host-facing entry points report as
-   SIFTMI_E_CAPACITY; the results that fit are valid.
+   SIFTMI_E_CAPACITY; the results that fit are valid.  Bit 5: a SIFTMI_FMT_GRAYF32 frame held a value outside [0, 1]
+   (SIFTMI_E_BADARG on the host-facing entry points; results unusable, see siftmi_format).
    Asynchronous on `stream` (a hipStream_t, NULL = the context's stream); no host sync.  The context's scratch is shared by
    all entry points: a following call on this context (any entry point, any stream) is ordered after this one on the
    device, and the introspection calls wait for it. */
@@ -429,7 +434,9 @@ int siftmi_get_timings(siftmi_ctx *ctx, double *ms /*[SIFTMI_T_COUNT]*/, int64_t
 /* the SIFTMI_T_BLUR time split by (octave, layer 1..nspo+2): accumulated ms and launch count of that layer's blur launches
    since the last reset -- one kernel instantiation and grid size each, so that a rocprofv3 kernel trace of the same command
    can be compared launch shape by launch shape; *marching: bit 0 = those launches use blur_ring_kernel (else blur2_kernel), bit 1 = they
-   also write the extrema scan's activity flags, bit 2 = the octave's layers come from blur_chain_kernel (1-3 under layer 1, 4-5 under 4) */
+   also write the extrema scan's activity flags, bit 2 = the octave's layers come from blur_chain_kernel: TWO launches produce its five layers, and their time and launch count
+   are booked on layers 1 (covering layers 1-3 and the next octave's layer 0) and 4 (layers 4-5) -- layers 2, 3 and 5 of such an
+   octave report 0 ms / 0 launches */
 int siftmi_get_blur_layer_timings(siftmi_ctx *ctx, int octave, int layer, double *ms, int64_t *launches, int32_t *marching);
 /* algorithmic bytes one blur launch of `octave` moves for ONE frame: 8 B per octave pixel */
 int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *ctx, int octave);
@@ -437,6 +444,16 @@ int64_t siftmi_blur_algorithmic_bytes(siftmi_ctx *ctx, int octave);
    decimated / activity-flag outputs the pipeline gives that layer) `iters` times on the resident pyramid and returns the
    mean kernel time in ms (hipEvents) */
 int siftmi_time_blur(siftmi_ctx *ctx, int octave, int layer, int iters, double *ms_per_launch);
+/* The two measured ceilings bench.py quotes the pyramid kernel against ("verify both peaks on the box"):
+   siftmi_time_copy        a plain float4 streaming copy inside the context's pyramid memory (`bytes` read and `bytes` written
+                           per launch, clipped to half the pyramid; *bytes_moved = read + written): the HBM rate a kernel
+                           with no arithmetic, no LDS and no halo reaches on THIS device now.  Invalidates the pyramid.
+   siftmi_time_blur_memory the same launch as siftmi_time_blur with both passes' arithmetic compiled out (same loads, LDS
+                           staging, barriers and stores; results are garbage): what the ring kernel's memory side alone
+                           sustains.  Default schedule's radii (5, 7, 8, 10, 13) on octaves that use the marching kernel only
+                           (SIFTMI_E_STATE otherwise).  Invalidates the pyramid. */
+int siftmi_time_copy(siftmi_ctx *ctx, int64_t bytes, int iters, double *ms_per_launch, int64_t *bytes_moved);
+int siftmi_time_blur_memory(siftmi_ctx *ctx, int octave, int layer, int iters, double *ms_per_launch);
 int siftmi_synchronize(siftmi_ctx *ctx);
 
 #ifdef __cplusplus

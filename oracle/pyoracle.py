@@ -67,6 +67,8 @@ def lib():
         L.so_extrema.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.so_refine.restype = C.c_int
         L.so_refine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.so_refine_stages.restype = C.c_int
+        L.so_refine_stages.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.so_orientations.restype = C.c_int
         L.so_orientations.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.so_orientation_histogram.restype = None
@@ -183,6 +185,16 @@ class Oracle:
         out = np.zeros(len(ext), keypoint_dtype)
         n = self.L.so_refine(self.h, o, _ptr(ext), len(ext), _ptr(out), len(out))
         return out[:n].copy()
+
+    def refine_stages(self, o, ext, contrast_terms=1):
+        """(keypoints, [pre-filter, converged, contrast, edge] survivor counts, rows [n, 4] = y, x, sigma, stage reached per
+        candidate); contrast_terms = 3: IPOL's three-term contrast instead of the reference's x-term-only one."""
+        ext = np.ascontiguousarray(ext)
+        out = np.zeros(len(ext), keypoint_dtype)
+        st = np.zeros(4, np.int32)
+        rows = np.zeros((len(ext), 4), np.float32)
+        n = self.L.so_refine_stages(self.h, o, _ptr(ext), len(ext), _ptr(out), len(out), _ptr(st), int(contrast_terms), _ptr(rows))
+        return out[:n].copy(), st.tolist(), rows
 
     def orientations(self, o, kp):
         kp = np.ascontiguousarray(kp)

@@ -476,7 +476,13 @@ static int out_of_bounds(int x, int y, int s, int w, int h, int scales) {
 }
 
 /* :193-300 siftInterpolate  +  SIFTOctave.interpolateKeypoints (SIFTOctave.swift:205-288) */
-int so_refine(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint *out, int cap) {
+/* stages[0..3] (optional): candidates that pass the 0.8 x threshold pre-filter / whose interpolation converges inside the
+ * volume / that pass the contrast test / that pass the edge test (= returned).  contrast_terms = 1: the reference's contrast
+ * (SIFTInterpolate.metal:89-100, x term only); 3: all three terms, v + 0.5 (dD . alpha), as IPOL's sift_anatomy does -- only for
+ * the stage-count comparison with the IPOL fixtures (tests/test_oracle_golden.py), never on a parity path.
+ * rows (optional, [n][4]): per input candidate (y, x, sigma, stage reached) in IPOL's units -- stage -1 = failed the pre-filter,
+ * 0 = passed it only (position = the sample), 1 = converged, 2 = passed the contrast test, 3 = returned (positions interpolated). */
+static int refine_impl(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint *out, int cap, int *stages, int contrast_terms, float *rows) {
     const so_octave *q = &c->oct[o];
     const dogtex t = {q->dog, q->w, q->h, c->cfg.nspo + 2, (size_t)q->w * q->h};
     /* SIFTOctave.swift:217-226 parameter literals */
@@ -488,7 +494,10 @@ int so_refine(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint
     for (int k = 0; k < n; k++) {
         int x = ext[k].x, y = ext[k].y, s = ext[k].scale;
         float value = dread(&t, x, y, s);
+        if (rows) { rows[4 * k] = (float)y * delta; rows[4 * k + 1] = (float)x * delta; rows[4 * k + 2] = q->sigmas[s]; rows[4 * k + 3] = -1.0f; }
         if (fabsf(value) <= dogThreshold * 0.8f) continue;         /* metal :208 */
+        if (stages) stages[0]++;
+        if (rows) rows[4 * k + 3] = 0.0f;
         if (out_of_bounds(x, y, s, q->w, q->h, scales)) continue;  /* :223 */
         int converged = 0;
         float alpha[3] = {0.0f, 0.0f, 0.0f};
@@ -509,14 +518,24 @@ int so_refine(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint
             i += 1;
         }
         if (dropped || !converged) continue;
+        if (stages) stages[1]++;
+        if (rows) {
+            rows[4 * k] = ((float)y + alpha[1]) * delta; rows[4 * k + 1] = ((float)x + alpha[0]) * delta;
+            rows[4 * k + 2] = q->sigmas[s] * powf(sigmaRatio, alpha[2]); rows[4 * k + 3] = 1.0f;
+        }
         {   /* :89-100 interpolateContrast: v + 0.5 * dDx * alpha.x (x term only) */
             float dD[3];
             derivatives3d(&t, x, y, s, dD);
             const float cx = dD[0] * alpha[0];
-            value = dread(&t, x, y, s) + cx * 0.5f;
+            if (contrast_terms == 3) value = dread(&t, x, y, s) + (cx + dD[1] * alpha[1] + dD[2] * alpha[2]) * 0.5f;
+            else value = dread(&t, x, y, s) + cx * 0.5f;
         }
         if (fabsf(value) <= dogThreshold) continue;                /* :282 */
+        if (stages) stages[2]++;
+        if (rows) rows[4 * k + 3] = 2.0f;
         if (is_on_edge(&t, x, y, s, edgeThreshold)) continue;      /* :287 */
+        if (stages) stages[3]++;
+        if (rows) rows[4 * k + 3] = 3.0f;
         if (count < cap && out) {
             so_keypoint *p = &out[count];                          /* SIFTOctave.swift:266-284 */
             p->octave = o;
@@ -533,6 +552,15 @@ int so_refine(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint
         count++;
     }
     return count;
+}
+
+int so_refine(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint *out, int cap) {
+    return refine_impl(c, o, ext, n, out, cap, NULL, 1, NULL);
+}
+
+int so_refine_stages(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint *out, int cap, int stages[4], int contrast_terms, float *rows) {
+    stages[0] = stages[1] = stages[2] = stages[3] = 0;
+    return refine_impl(c, o, ext, n, out, cap, stages, contrast_terms == 3 ? 3 : 1, rows);
 }
 
 /* ---------------------------------------------------------------------------------------------

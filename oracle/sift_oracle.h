@@ -93,6 +93,10 @@ const float *so_seed(const so_ctx *c);                     /* octave-0 layer 0  
 /* keypoint stages, per octave; return the count (which may exceed cap: nothing past cap is written) */
 int so_extrema(const so_ctx *c, int o, so_extremum *out, int cap);
 int so_refine(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint *out, int cap);
+/* so_refine with per-stage survivor counts (pre-filter, converged, contrast, edge) and, with contrast_terms = 3, IPOL's
+   three-term contrast instead of the reference's x-term-only one: for the stage-by-stage comparison with the IPOL fixtures */
+int so_refine_stages(const so_ctx *c, int o, const so_extremum *ext, int n, so_keypoint *out, int cap, int stages[4], int contrast_terms,
+                     float *rows /* optional [n][4]: y, x, sigma (IPOL units), stage reached (-1 ... 3) per input candidate */);
 int so_orientations(const so_ctx *c, int o, const so_keypoint *kp, int n, so_orientation *out, int cap);
 /* test hook: smoothed 36-bin orientation histogram of one keypoint */
 void so_orientation_histogram(const so_ctx *c, int o, const so_keypoint *kp, float *hist36);

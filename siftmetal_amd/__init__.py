@@ -334,6 +334,18 @@ class Engine:
         _capi.check(self.L.siftmi_time_blur(self.h, o, layer, iters, C.byref(v)))
         return v.value
 
+    def time_copy(self, nbytes, iters=10):
+        """(ms per launch, bytes moved per launch) of a plain float4 copy inside the pyramid memory: the measured HBM ceiling."""
+        v, n = C.c_double(), C.c_int64()
+        _capi.check(self.L.siftmi_time_copy(self.h, int(nbytes), iters, C.byref(v), C.byref(n)))
+        return v.value, int(n.value)
+
+    def time_blur_memory(self, o, layer, iters=10):
+        """ms per launch of the layer's ring kernel with its arithmetic compiled out (loads, LDS staging, barriers, stores only)."""
+        v = C.c_double()
+        _capi.check(self.L.siftmi_time_blur_memory(self.h, o, layer, iters, C.byref(v)))
+        return v.value
+
     def synchronize(self):
         _capi.check(self.L.siftmi_synchronize(self.h))
 

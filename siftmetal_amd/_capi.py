@@ -18,7 +18,7 @@ EXPORTS = [
     "siftmi_descriptor_to_reference", "siftmi_host_alloc", "siftmi_host_free", "siftmi_match_descriptors", "siftmi_approximate_match", "siftmi_match_geometry", "siftmi_descriptor_index", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
     "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_dog", "siftmi_copy_extrema", "siftmi_copy_orientations",
     "siftmi_copy_descriptor_floats", "siftmi_enable_timings", "siftmi_reset_timings", "siftmi_get_timings",
-    "siftmi_blur_algorithmic_bytes", "siftmi_get_blur_layer_timings", "siftmi_time_blur", "siftmi_synchronize",
+    "siftmi_blur_algorithmic_bytes", "siftmi_get_blur_layer_timings", "siftmi_time_blur", "siftmi_time_copy", "siftmi_time_blur_memory", "siftmi_synchronize",
     "siftmi_device_alloc", "siftmi_device_free", "siftmi_memcpy", "siftmi_device_synchronize",
     "siftmi_stream_default_config", "siftmi_stream_create", "siftmi_stream_destroy", "siftmi_stream_context",
     "siftmi_stream_submit_device", "siftmi_stream_submit_host", "siftmi_stream_wait_upload", "siftmi_stream_wait_consumed",
@@ -143,6 +143,8 @@ def load():
     L.siftmi_blur_algorithmic_bytes.argtypes = [vp, C.c_int]
     L.siftmi_blur_algorithmic_bytes.restype = C.c_int64
     L.siftmi_time_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.siftmi_time_copy.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.siftmi_time_blur_memory.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.siftmi_synchronize.argtypes = [vp]
     i64p = C.POINTER(C.c_int64)
     L.siftmi_device_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp)]

@@ -135,6 +135,14 @@ __device__ __forceinline__ float seed_sample(const unsigned char *frame, const S
     return fx * (fy * c0 + (1.0f - fy) * c1) + (1.0f - fx) * (fy * c2 + (1.0f - fy) * c3);
 }
 
+// Streaming hints of the ring kernel's global traffic (bit 0: row stores non-temporal, bit 1: row loads non-temporal).  A layer
+// is written once and next read 4 GB later (64 frames), far beyond L2 + Infinity Cache, so its lines need not stay cached:
+// non-temporal row stores took 2.7-3.1 % off the memory-bound R = 5 layer and nothing off R = 13 (round 4, tools/ubench/blur_variants
+// built with -DSIFTMI_RING_NT=0...3, two interleaved passes on one box: 0.431 / 0.427 -> 0.418 / 0.415 ms per 32 x 3840x2160);
+// non-temporal LOADS cost 6-17 % -- the 25 % halo columns a strip shares with its neighbours are L2 hits only while they stay cached.
+#ifndef SIFTMI_RING_NT
+#define SIFTMI_RING_NT 1
+#endif
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0), which
 // drains every outstanding global load and store at each barrier -- fatal for kernels that keep
 // prefetches in flight across phases (the marching blur lost its whole load/compute overlap to it).
@@ -158,6 +166,14 @@ struct VTaps {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ring_store2(float *p, f32x2 v) {
+    if (SIFTMI_RING_NT & 1) __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(p));
+    else *reinterpret_cast<f32x2 *>(p) = v;
+}
+__device__ __forceinline__ f32x4 ring_load4(const float *p) {
+    if (SIFTMI_RING_NT & 2) return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return *reinterpret_cast<const f32x4 *>(p);
+}
 typedef __attribute__((address_space(3))) volatile f32x2 lds_cv_f32x2;
 typedef __attribute__((address_space(3))) volatile float lds_cv_f32;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -169,7 +185,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x4 load_quad_mirrored(const float *rowp, int gx, int w) {
     const bool mir = gx < 0 || gx >= w;
     const int g2 = min(max(gx < 0 ? -gx - 4 : (gx >= w ? 2 * w - 4 - gx : gx), 0), w - 4);
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + g2);
+    const f32x4 v = ring_load4(rowp + g2);
     f32x4 r;
     r.x = mir ? v.w : v.x; r.y = mir ? v.z : v.y; r.z = mir ? v.y : v.z; r.w = mir ? v.x : v.w;
     return r;
@@ -765,8 +781,9 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
             if constexpr (HPIPE) {
                 // Two items per trip, both items' LDS reads issued before the first FMA: the second item's read latency runs
                 // under the first item's 8 (2R + 1) FMAs instead of in front of its own (a row is still read and written by one
-                // wavefront within one trip, so the in-place update stays safe).  Needs ~2 x 32 operand registers: R >= 9 only,
-                // where three workgroups per CU leave 168 VGPRs per lane.
+                // wavefront within one trip, so the in-place update stays safe).  Two items' operands (2 x (16 + 2R) registers) fit the
+                // 128-VGPR budget of four workgroups per CU up to R = 8, which is where the template default turns it on (R <= 7, and
+                // R = 8 unless DEC && ACT); at R >= 9 it needs the 168 VGPRs of three workgroups per CU and measured no gain there.
 #pragma unroll 1
                 for (int item = tid; item < n_items; item += 2 * G::NTHR) {
                     float va[4 * (M1 - M0)], vb[4 * (M1 - M0)];
@@ -937,7 +954,7 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
                 if (!FULL && gy >= h) continue;
                 float *o = out + (size_t)gy * w + gx;
                 if (FULL || (gx + 1 < w && (w & 1) == 0)) {
-                    *reinterpret_cast<f32x2 *>(o) = acc[rr];
+                    ring_store2(o, acc[rr]);
                 } else {
                     if (gx + 0 < w) o[0] = acc[rr].x;
                     if (gx + 1 < w) o[1] = acc[rr].y;
@@ -1003,6 +1020,35 @@ __global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__res
 #pragma unroll
         for (int k = 0; k < 8; k++) d[k] = dsum[k];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SIFTMI_FMT_GRAYF32 input contract (include/siftmi.h): every pixel in [0, 1].  One pass over the frames of a sub-batch (4 B per
+// input pixel, float input only); any value outside the range, or a NaN, sets bit 5 of the call's overflow flags.
+__global__ __launch_bounds__(256) void check_unit_range_kernel(const unsigned char *__restrict__ pixels, size_t row_stride, size_t frame_stride,
+                                                              int w, int h, int n_frames, int32_t *__restrict__ flags) {
+    const long long total = (long long)w * h * n_frames;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int f = (int)(i / ((long long)w * h));
+        const int r = (int)(i - (long long)f * w * h);
+        const int y = r / w, x = r - y * w;
+        const float v = *reinterpret_cast<const float *>(pixels + (size_t)f * frame_stride + (size_t)y * row_stride + 4 * (size_t)x);
+        bad = bad || !(v >= 0.0f && v <= 1.0f);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Plain float4 streaming copy: the measured HBM ceiling bench.py quotes the pyramid kernel against (siftmi_time_copy).
+// One float4 per lane, one pass, workgroups in address order -- the fastest of the forms tools/ubench/ubench_copy.hip compares on
+// this hardware (6.2 TB/s; 6.5 with non-temporal loads and stores; grid-stride loops and several float4 per lane: 4.3-5.8).
+template <bool NT>
+__global__ __launch_bounds__(256) void copy_f4_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    else dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------

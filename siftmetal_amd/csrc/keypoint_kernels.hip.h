@@ -648,7 +648,14 @@ __global__ __launch_bounds__(1024) void kp_row_sort_small_kernel(PyramidDesc P, 
 // -- the descriptor loop converts 8 values per sample.  Resolution 2.3e-10 per contribution, unbiased: a bin of a few hundred
 // contributions carries ~2e-9 of absolute error against bin totals of 0.01 ... 30, still two orders below the f32 sums of
 // the reference.  Bin totals stay below 2^10, i.e. 2^42 here.
-__device__ __forceinline__ unsigned long long fix32_product(float p, float v32) { return (unsigned long long)(unsigned)fmaf(p, v32, 0.5f); }
+// The conversion is the hardware instruction itself (v_cvt_u32_f32 saturates out-of-range and negative inputs and maps NaN to 0),
+// not a C++ float -> unsigned cast, which is undefined out of range: a frame that breaks the [0, 1] input contract (SIFTMI_FMT_GRAYF32,
+// reported by check_unit_range_kernel) then gives saturated histograms, not poison.
+__device__ __forceinline__ unsigned long long fix32_product(float p, float v32) {
+    unsigned r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(fmaf(p, v32, 0.5f)));
+    return (unsigned long long)r;
+}
 __device__ __forceinline__ float from_fix32(unsigned long long v) { return (float)v * 2.3283064365386963e-10f; }
 
 // atan2(y, x) of finite arguments for the sample loops (their VALU count is the limit of the orientation and descriptor

@@ -725,6 +725,12 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
         else hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, st, c->d_counters, n_cnt);
         c->zero_job = ZeroJob{nullptr, 0, nullptr, 0};
     }
+    if (format == SIFTMI_FMT_GRAYF32) {                       // input contract of float frames (siftmi_format); after the counters were cleared
+        const long long px = (long long)c->cfg.width * c->cfg.height * nf;
+        hipLaunchKernelGGL(check_unit_range_kernel, dim3((unsigned)std::min<long long>((px + 255) / 256, 4096)), dim3(256), 0, st, (const unsigned char *)d_pixels,
+                           row_stride, frame_stride, c->cfg.width, c->cfg.height, nf, &c->d_state->overflow_flags);
+        HIP_TRY(hipGetLastError());
+    }
     hipStream_t cur = st;
     bool joined[MAX_OCT] = {};
     for (int o = 0; o < c->n_oct; o++) {
@@ -990,14 +996,21 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
                 c->raw_exact = hit.raw_exact;                     // a replay does not run the host code that sets it
                 break;
             }
-        if (!exec && seen) {
-            if (c->gcache.size() >= graph_cache_max()) {
-                // full: the least recently used signature goes (round 2 stopped capturing for good here, so a context that had
-                // met 64 signatures ran every new one with direct launches)
+        // A full cache evicts its least recently used signature -- but only on a runtime whose hipGraphExecDestroy is safe
+        // (graph_destroy_safe): on an older one an evicted graph can only be abandoned (a few hundred kB each), so a long-running
+        // caller whose buffers keep changing would leak without bound.  There the cache simply stops growing and new signatures
+        // run as direct launches (round 2's behaviour).
+        bool may_capture = seen;
+        if (!exec && seen && c->gcache.size() >= graph_cache_max()) {
+            if (graph_destroy_safe()) {
                 (void)hipDeviceSynchronize();                  // it may still be running
                 retire_exec(c->gcache.front().exec);
                 c->gcache.erase(c->gcache.begin());
+            } else {
+                may_capture = false;
             }
+        }
+        if (!exec && may_capture) {
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
@@ -1051,6 +1064,9 @@ static int grow_outputs(siftmi_ctx *c, long long kp_need, long long desc_need) {
 }
 
 static int overflow_error(siftmi_ctx *c, int flags) {
+    if (flags & 32)
+        return set_error(SIFTMI_E_BADARG, "SIFTMI_FMT_GRAYF32 frame with a value outside [0, 1] (or a NaN): float input is the luma a unorm texture "
+                                          "delivers; rescale it (include/siftmi.h, siftmi_format)");
     std::string what;
     if (flags & 1) what += " extrema(max_extrema)";
     if (flags & 2) what += " keypoints(max_keypoints)";
@@ -1184,11 +1200,11 @@ extern "C" int siftmi_detect(siftmi_ctx *c, const void *pixels, int format, size
     if ((rc = run_dense_detect(c, st, 1, d_px, format, d_row, d_frame, false, true))) return rc;
     if ((rc = input_consumed(c, on_device))) return rc;
     if ((rc = run_refine(c, st, 1))) return rc;
-    std::vector<int32_t> h(5 * (size_t)c->B * c->n_oct);
+    std::vector<int32_t> h(5 * (size_t)c->B * c->n_oct + sizeof(PackState) / sizeof(int32_t));   // the counters and, behind them, the PackState
     HIP_TRY(hipMemcpyAsync(h.data(), c->d_counters, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const size_t cs = (size_t)c->B * c->n_oct;
-    int flags = 0;
+    int flags = h[5 * cs + 2] & 32;                         // PackState.overflow_flags: the float-input range check
     size_t total = 0;
     c->h_stats.assign(5 * (size_t)c->n_oct, 0);
     for (int o = 0; o < c->n_oct; o++) {
@@ -1657,6 +1673,98 @@ extern "C" int siftmi_time_blur(siftmi_ctx *c, int o, int layer, int iters, doub
     *ms_per_launch = (double)ms / iters;
     return SIFTMI_OK;
 }
+extern "C" int siftmi_time_copy(siftmi_ctx *c, int64_t bytes, int iters, double *ms_per_launch, int64_t *bytes_moved) {
+    if (!c || !ms_per_launch || bytes < 4096 || iters < 1) return set_error(SIFTMI_E_BADARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t half = ((size_t)c->B * c->frame_stride * sizeof(float) / 2) & ~(size_t)4095;
+    const size_t n = std::min<size_t>((size_t)bytes, half) & ~(size_t)15;
+    if (n < 4096) return set_error(SIFTMI_E_STATE, "pyramid too small for a copy measurement");
+    {
+        const int rc0 = order_begin(c, c->stream);
+        if (rc0) return rc0;
+    }
+    c->pyramid_valid = false;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(c->d_gauss);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(c->d_gauss) + half);
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    const dim3 grid((unsigned)((n / 16 + 255) / 256));
+    float best = 0.0f;
+    for (int nt = 0; nt < 2; nt++) {                          // plain and non-temporal: the ceiling is the faster of the two
+        auto launch = [&]() {
+            if (nt) hipLaunchKernelGGL(copy_f4_kernel<true>, grid, dim3(256), 0, c->stream, src, dst, n / 16);
+            else hipLaunchKernelGGL(copy_f4_kernel<false>, grid, dim3(256), 0, c->stream, src, dst, n / 16);
+        };
+        launch();                                              // warm-up (clocks, TLB)
+        HIP_TRY(hipEventRecord(a, c->stream));
+        for (int i = 0; i < iters; i++) launch();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b, c->stream));
+        HIP_TRY(hipEventSynchronize(b));
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, a, b));
+        if (nt == 0 || t < best) best = t;
+    }
+    const float ms = best;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = (double)ms / iters;
+    if (bytes_moved) *bytes_moved = 2 * (int64_t)n;
+    return order_end(c, c->stream);
+}
+
+// the ring kernel of `layer` with its arithmetic compiled out (blur_ring_kernel's DBG = 8 | 16)
+template <int R>
+static hipError_t launch_ring_memory_only(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf, const TapWeights &wt) {
+    using Gr = RingGeom<R>;
+    SeedSource none; memset(&none, 0, sizeof(none));
+    Decimate nodec; memset(&nodec, 0, sizeof(nodec));
+    const int chr = march_chunk_rows(h);
+    const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
+    hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, false, false, 24>), dim3(((total + 7) / 8) * 8), dim3(Gr::NTHR), Gr::lds_bytes, st, src, dst, w, h,
+                       c->frame_stride, c->frame_stride, wt, nf, chr, nodec, Activity{nullptr, 0, 0, 0.0f}, none);
+    return hipGetLastError();
+}
+
+extern "C" int siftmi_time_blur_memory(siftmi_ctx *c, int o, int layer, int iters, double *ms_per_launch) {
+    if (!c || !ms_per_launch || o < 0 || o >= c->n_oct || layer < 1 || layer > c->nspo + 2 || iters < 1)
+        return set_error(SIFTMI_E_BADARG, "bad argument");
+    if (!uses_march(c, c->ow[o], c->oh[o], c->B)) return set_error(SIFTMI_E_STATE, "octave %d does not use the marching kernel at this batch size", o);
+    HIP_TRY(hipSetDevice(c->device));
+    const int R = (c->taps[layer - 1] - 1) / 2;
+    {
+        const int rc0 = order_begin(c, c->stream);
+        if (rc0) return rc0;
+    }
+    c->pyramid_valid = false;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, c->stream));
+    for (int i = 0; i < iters; i++) {
+        hipError_t e = hipErrorInvalidValue;
+        const float *src = gauss_ptr(c, o, layer - 1);
+        float *dst = gauss_ptr(c, o, layer);
+        switch (R) {
+            case 5: e = launch_ring_memory_only<5>(c, c->stream, src, dst, c->ow[o], c->oh[o], c->B, c->layer_w[layer - 1]); break;
+            case 7: e = launch_ring_memory_only<7>(c, c->stream, src, dst, c->ow[o], c->oh[o], c->B, c->layer_w[layer - 1]); break;
+            case 8: e = launch_ring_memory_only<8>(c, c->stream, src, dst, c->ow[o], c->oh[o], c->B, c->layer_w[layer - 1]); break;
+            case 10: e = launch_ring_memory_only<10>(c, c->stream, src, dst, c->ow[o], c->oh[o], c->B, c->layer_w[layer - 1]); break;
+            case 13: e = launch_ring_memory_only<13>(c, c->stream, src, dst, c->ow[o], c->oh[o], c->B, c->layer_w[layer - 1]); break;
+            default: break;
+        }
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+            return set_error(SIFTMI_E_STATE, "no memory-only instantiation for radius %d (default schedule only)", R);
+        }
+    }
+    HIP_TRY(hipEventRecord(b, c->stream));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = (double)ms / iters;
+    return order_end(c, c->stream);
+}
+
 extern "C" int siftmi_synchronize(siftmi_ctx *c) {
     if (!c) return set_error(SIFTMI_E_BADARG, "null ctx");
     HIP_TRY(hipSetDevice(c->device));

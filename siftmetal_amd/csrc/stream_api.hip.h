@@ -384,6 +384,7 @@ extern "C" int siftmi_stream_result_host(siftmi_stream *s, int back, siftmi_step
     out->keypoints = rs.h_kp.data(); out->descriptors = rs.h_desc.data();
     out->counts = rs.h_meta + 4;
     out->n_keypoints = rs.nk; out->n_descriptors = rs.nd; out->overflow_flags = rs.flags; out->reserved = 0;
+    if (rs.flags & 32) return set_error(SIFTMI_E_BADARG, "step %lld: SIFTMI_FMT_GRAYF32 frame with a value outside [0, 1] (include/siftmi.h, siftmi_format)", (long long)rs.step);
     if (rs.flags) return set_error(SIFTMI_E_CAPACITY, "list capacity exceeded in step %lld (overflow flags 0x%x): results truncated", (long long)rs.step, rs.flags);
     return SIFTMI_OK;
 }

@@ -286,6 +286,8 @@ class FrameStream:
         back = (1 if previous else 0) if back is None else back
         r = _capi.StepHost()
         _capi.check(self.L.siftmi_stream_result_host(self.h, back, C.byref(r)), allow_capacity=True)
+        if r.overflow_flags & 32:                            # a float frame outside [0, 1]: results unusable (siftmi_format)
+            raise _capi.SiftmiError(_capi.E_BADARG, "SIFTMI_FMT_GRAYF32 frame with a value outside [0, 1]")
         if r.overflow_flags and not allow_capacity:          # the condition the host-facing API reports as SIFTMI_E_CAPACITY
             raise _capi.SiftmiError(_capi.E_CAPACITY, "list capacity exceeded on the device path (overflow flags 0x%x): results truncated" % r.overflow_flags)
         nk, nd = r.n_keypoints, r.n_descriptors

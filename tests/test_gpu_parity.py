@@ -109,6 +109,66 @@ def test_butterfly_against_ipol_fixtures(sm, butterfly_bgra, ipol):
     assert eng26.stats()["raw_extrema"][0].tolist() == [1880, 904, 224, 52, 8]
 
 
+def test_ipol_soft_threshold_and_stage_known_answers_hip(sm, butterfly_bgra, ipol):
+    """The IPOL stage files on the HIP path (the CPU twin with the stage-by-stage table: tests/test_oracle_golden.py::
+    test_ipol_stage_fixtures_...).  With the 26-neighbour switch the extrema kernel's candidate list -- 3-D extrema with
+    |DoG| > 0.8 x 0.0133 -- must be IPOL's 2130 extra_DoGSoftThresh rows at the same (y, x, sigma) plus the same 4 borderline
+    rows the restatement adds, and refinement must return the restatement's 1287 keypoints, every one a row of extra_OnEdgeResp."""
+    eng = sm.Engine(512, 340, n_octaves=5, full_neighbourhood=1)
+    kps, counts = eng.detect(butterfly_bgra)
+    pos, gold_in = [], []
+    gold = ipol["dog_soft"].astype(np.float64)
+    for o in range(5):
+        e = eng.extrema(o)
+        w, h, d = eng.octave_size(o)
+        pos.append(np.stack([e["y"] * d, e["x"] * d, [eng.sigma(o, int(sc)) for sc in e["scale"]]], 1))
+        # the kernel's list also applies the refinement-entry border test (5 samples, SIFTInterpolate.metal:223), which IPOL
+        # applies later: IPOL's rows of this octave (sigma in [sigma_1, sigma_3]) that lie inside the border
+        sg = gold[:, 2]
+        in_oct = (sg > eng.sigma(o, 1) * 0.999) & (sg < eng.sigma(o, 3) * 1.001)
+        gy, gx = gold[:, 0] / d, gold[:, 1] / d
+        gold_in.append(gold[in_oct & (gx >= 5) & (gx <= w - 6) & (gy >= 5) & (gy <= h - 6)])
+    pos, gold_in = np.concatenate(pos).astype(np.float64), np.concatenate(gold_in)
+    assert len(gold) == 2130 and len(pos) == 2122 and len(gold_in) == 2118
+    dist = np.abs(pos[:, None, :] - gold_in[None]).max(-1)
+    assert (dist.min(0) < 2e-3).all() and (dist.min(1) >= 2e-3).sum() == 4      # IPOL's rows, and the 4 borderline extras of the CPU twin
+    assert int(counts.sum()) == 1287
+    ours = np.stack([kps["abs_y"], kps["abs_x"]], 1).astype(np.float64)
+    d2 = np.abs(ours[:, None, :] - ipol["on_edge"][:, :2].astype(np.float64)[None]).max(-1)
+    assert (d2.min(1) < 0.01).sum() >= 1286
+    eng.close()
+
+
+def test_float_frames_outside_the_unit_range_are_reported(sm):
+    """SIFTMI_FMT_GRAYF32 is the luma a unorm texture delivers, [0, 1] (include/siftmi.h).  The orientation / descriptor histograms
+    accumulate in 2^-32 fixed point and would saturate silently for 0 ... 255 input: such a frame is reported
+    (SIFTMI_E_BADARG on the host-facing calls, overflow flag bit 5 on the device path), a normalised one gives the gray-8 results."""
+    from siftmetal_amd import _capi, stream as smstream
+    g8 = blob_frame(320, 240, 4, gray=True)
+    unit = (g8.astype(np.float32) / np.float32(255)).astype(np.float32)
+    eng = sm.Engine(320, 240, n_octaves=3, max_batch=2)
+    want = eng.detect_describe_batch(g8[None])
+    got = eng.detect_describe_batch(unit[None])
+    assert got[0].tobytes() == want[0].tobytes() and got[2].tobytes() == want[2].tobytes() and len(got[2]) > 20
+    for bad in (unit * np.float32(255), unit - np.float32(0.5), np.where(np.arange(320) == 7, np.float32(np.nan), unit).astype(np.float32)):
+        with pytest.raises(sm.SiftmiError) as e:
+            eng.detect_describe_batch(np.ascontiguousarray(bad)[None])
+        assert e.value.code == _capi.E_BADARG and "[0, 1]" in str(e.value)
+        with pytest.raises(sm.SiftmiError) as e:
+            eng.detect(np.ascontiguousarray(bad))
+        assert e.value.code == _capi.E_BADARG
+    # the second frame of a batch, on the device path: flag bit 5 in the totals
+    fs = smstream.FrameStream(eng, 2, fmt=_capi.FMT_GRAYF32)
+    fs.run(smstream.DeviceFrames(np.stack([unit, unit * np.float32(3)])))
+    with pytest.raises(sm.SiftmiError) as e:
+        fs.results_host()
+    assert e.value.code == _capi.E_BADARG
+    fs.run(smstream.DeviceFrames(np.stack([unit, unit])))
+    assert fs.results_host()["overflow_flags"] == 0
+    assert eng.detect_describe_batch(unit[None])[2].tobytes() == want[2].tobytes()       # and the context keeps working
+    fs.close(); eng.close()
+
+
 def test_api_getKeypoints_getDescriptors_roundtrip(sm, butterfly_bgra):
     """SIFT.getKeypoints / getDescriptors (SIFT.swift:147, :207) through the object API, incl. a
     caller-filtered keypoint list; must equal the fused batch path."""
@@ -1107,6 +1167,10 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] and r["traffic"] > r["algorithmic_bytes_per_launch_avg"]
+    # the ceilings are measured in the run, not constants: a float4 copy and the ring kernel without arithmetic
+    assert 3000 < r["peak_measured"] < 8000 and abs(r["frac_of_measured"] - r["achieved"] / r["peak_measured"]) < 1e-3
+    assert len(r["memory_only_GBps_by_layer"]) == 5 and all(v > r["octave0_GBps_by_layer"][k] for k, v in r["memory_only_GBps_by_layer"].items())
+    assert r["seed"]["launches"] == 2 and r["seed"]["algorithmic_bytes_per_launch"] == 20 * 1920 * 1080 * 64 and 0.2 < r["seed"]["frac"] < 1
     shapes = r["by_launch_shape"]
     assert len(shapes) == 20 and shapes["o0_l5"]["kernel"].startswith("blur_ring_kernel<13") and shapes["o0_l3"]["decimating"]
     assert "workload" in d["config"] and "model" not in d["config"]

@@ -90,7 +90,7 @@ static void bench_R(Ctx &c, float rho) {
             double sum[8] = {0}; for (size_t i = 0; i < d.size(); i++) sum[i & 7] += (double)d[i]; double tot = 0; for (int k = 0; k < 8; k++) tot += sum[k]; \
             const char *nm[8] = {"issue", "H", "B2wait", "V", "stores", "B3wait", "vmwait+ldsw", "B1wait"}; \
             printf("      stamps (cycles per wave-step, share):"); for (int k = 0; k < 8; k++) printf(" %s %.0f (%.0f%%)", nm[k], sum[k] / ((double)tx * c.nf * ((c.h + S_ - 1) / S_) * 4) , 100.0 * sum[k] / tot); printf("\n"); } }
-    VR(32, 128, 4, 0) VR(32, 256, 4, 0)
+    VR(32, 128, 4, 0) VR(32, 256, 4, 0) VR(32, 256, 4, 24)
 #define VRH4(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
