@@ -486,8 +486,9 @@ def main():
         # the metric as SURVEY.md 8d words it: frames cross PCIe from pinned host memory, packed results are copied back
         pin = sm.pinned_empty(frames_np.shape, np.uint8)
         pin[...] = frames_np
-        # its own context with 16-frame sub-batches: the H2D copy of sub-batch i+1 runs under the kernels of sub-batch i
-        eio = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=16)
+        # its own context with 8-frame sub-batches (the first one 2 frames): the H2D copy of sub-batch i+1 runs under the kernels of
+        # sub-batch i, the packed results of finished sub-batches are copied back under the later ones
+        eio = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=8)
         eio.detect_describe_batch(pin, copy=False)
         reps = 3
         t1 = time.perf_counter()
@@ -495,7 +496,9 @@ def main():
             k, kc, d, dc = eio.detect_describe_batch(pin, copy=False)
         ms_io = (time.perf_counter() - t1) / reps * 1e3
         out["config"]["host_io"] = {"workload": "the same %d-frame step through siftmi_detect_describe_batch: BGRA8 frames in pinned host memory "
-                                                "(16-frame sub-batches: the H2D copy of sub-batch i+1 runs under the kernels of sub-batch i), packed keypoints + descriptors copied back" % F,
+                                                "(8-frame sub-batches, captured launch sequences: the H2D copy of sub-batch i+1 runs under the kernels of sub-batch i, results of finished "
+                                                "sub-batches are copied back under the later ones); a synchronous call cannot hide its first upload or its last sub-batch: "
+                                                "time >= max(upload + last sub-batch, first upload + all kernels)" % F,
                                     "ms_per_step": round(ms_io, 4), "Mpixels_per_s": round(F * W * H / ms_io / 1e3, 1),
                                     "h2d_bytes_per_step": int(pin.nbytes), "d2h_bytes_per_step": int(k.nbytes + d.nbytes),
                                     "keypoints": int(len(k)), "descriptors": int(len(d))}

@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
         // One sample (j = x offset, i = y offset) of the window: SIFTDescriptor.metal:197-222.  INTERIOR (wave-uniform, almost
         // every descriptor): the sample and its four neighbours are inside the image, so the gradient is four loads at one
         // 32-bit offset (the rows above and below through an SGPR addend) and there is no per-sample range test or mirror.
-        auto sample = [&](auto interior_tag, int j, int i) {
+        auto sample = [&](auto interior_tag, int j, int i, float t_xp, float t_xm, float t_yp, float t_ym) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
             const float fj = (float)j, fi = (float)i;
             const float rx = fmaf(fj, cs, -(fi * sn));                     // (j cosT - i sinT) / histogramWidth
@@ -1077,9 +1077,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
             if (bx <= -1.0f || bx >= 4.0f || by <= -1.0f || by >= 4.0f) return;
             float dx, dy;                                                  // central differences, not yet halved
             if (INTERIOR) {
-                const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
-                dx = layer_ld_s(g, c + 8, g.pitch) - layer_ld_s(g, c, g.pitch);
-                dy = layer_ld_s(g, c + 4, 2 * g.pitch) - layer_ld(g, c + 4);
+                dx = t_xp - t_xm;                                          // the four texels were requested one trip ahead (walk)
+                dy = t_yp - t_ym;
             } else {
                 // ushort2(px + j, py + i): truncation toward zero, (-1, 0) -> 0; negative: no texel
                 const float fx = px + fj, fy = py + fi;
@@ -1123,6 +1122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
             }
         };
         auto walk = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
             int cur = 0;                                                   // window row of this lane's current sample
             if (compact && lidx < total) {                                 // binary search once, then only advance
                 int lo_c = 0, hi_c = side - 1;                             // last row whose start <= lidx
@@ -1130,8 +1130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
                 cur = lo_c;
             }
             int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
-            for (int idx = lidx; idx < total; idx += STRIDE) {
-                int j, i;                                                  // j: x offset (inner), i: y offset (outer)
+            auto locate = [&](int idx, int &j, int &i) {                   // j: x offset (inner), i: y offset (outer); idx never decreases
                 if (compact) {
                     while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty rows have equal starts
                     i = cur - radius;
@@ -1140,7 +1139,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
                     const int ii = idx / side;
                     i = ii - radius; j = idx - ii * side - radius;
                 }
-                sample(interior_tag, j, i);
+            };
+            if constexpr (INTERIOR) {
+                // Software-pipelined (round 4): the four texels of the NEXT candidate are requested before the current one is
+                // turned into its eight histogram adds, so a lane's memory latency runs under ~130 vector instructions and the LDS
+                // atomics of the sample before instead of in front of them.  The request is unconditional (past the last candidate
+                // the last one is fetched again; a candidate that fails the cell-range test below costs four L2 hits): no branch
+                // around a vector-memory instruction, so the compiler's vmcnt count stays exact (vmcnt(4) at the use).
+                if (lidx >= total) return;
+                auto fetch = [&](int j, int i, float &t_xp, float &t_xm, float &t_yp, float &t_ym) {
+                    const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
+                    t_xp = layer_ld_s(g, c + 8, g.pitch); t_xm = layer_ld_s(g, c, g.pitch);
+                    t_yp = layer_ld_s(g, c + 4, 2 * g.pitch); t_ym = layer_ld(g, c + 4);
+                };
+                int j, i;
+                float a0, a1, a2, a3;
+                locate(lidx, j, i);
+                fetch(j, i, a0, a1, a2, a3);
+                for (int idx = lidx; idx < total; idx += STRIDE) {
+                    int jn, in_;
+                    float b0, b1, b2, b3;
+                    locate(min(idx + STRIDE, total - 1), jn, in_);
+                    fetch(jn, in_, b0, b1, b2, b3);
+                    sample(interior_tag, j, i, a0, a1, a2, a3);
+                    j = jn; i = in_; a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                }
+            } else {
+                for (int idx = lidx; idx < total; idx += STRIDE) {
+                    int j, i;
+                    locate(idx, j, i);
+                    sample(interior_tag, j, i, 0.0f, 0.0f, 0.0f, 0.0f);
+                }
             }
         };
         if (interior) walk(std::true_type{}); else walk(std::false_type{});

@@ -76,6 +76,22 @@ struct StageRange {                            // host-side range around the lau
     ~StageRange() { if (on) roctx().pop(); }
 };
 
+// Streams that only carry PCIe copies (uploads of host frames, copy-back of results).  The runtime multiplexes a process's streams
+// onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and a forked launch graph of four octave chains occupies all of
+// them: a copy stream that shares a queue with a chain has its barrier packets queued behind that chain's kernels, and the upload
+// of sub-batch i + 1 then starts when sub-batch i has FINISHED instead of under it (round 4: 64 x 1080p through 16-frame sub-batches
+// 19.7 ms forked against 14.8 ms with the serial graph).  Streams of another priority get hardware queues of their own, so the
+// copy streams are created at the highest priority -- they launch no kernels, so they take no CUs from anybody.
+// SIFTMI_COPY_STREAM_PRIORITY=0 restores plain streams.
+static hipError_t create_copy_stream(hipStream_t *s) {
+    static const int mode = [] { const char *e = getenv("SIFTMI_COPY_STREAM_PRIORITY"); return e ? atoi(e) : 0; }();
+    int least = 0, greatest = 0;
+    if (mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 struct EventPair { hipEvent_t a, b; int stage; int sub; };     // sub: octave * 8 + layer for the layer blurs, else -1
 
 struct siftmi_ctx {
@@ -139,6 +155,11 @@ struct siftmi_ctx {
     };
     PinnedBuf<siftmi_keypoint> h_kp;
     PinnedBuf<siftmi_descriptor> h_desc;
+    // siftmi_detect_describe_batch: running totals after every sub-batch (pinned, 4 ints each) + the event that says they have
+    // arrived, and the stream the packed records of finished sub-batches are copied back on while later sub-batches compute
+    PinnedBuf<int32_t> h_sub;
+    std::vector<hipEvent_t> ev_sub;
+    hipStream_t d2h_stream = nullptr;
     std::vector<int32_t> h_counts, h_stats;
     std::vector<siftmi_match> h_matches;
     DescriptorRec *d_match_src = nullptr, *d_match_tgt = nullptr; long long match_src_cap = 0, match_tgt_cap = 0;
@@ -161,9 +182,11 @@ struct siftmi_ctx {
     struct GraphKey {
         const void *px; int n_frames, format; size_t row_stride, frame_stride; void *kp; long long kp_cap; void *desc; long long desc_cap;
         void *counts, *totals; hipStream_t st;
+        int frame_base, total_frames;              // a sub-batch of the host-fed call (frames frame_base ... of total_frames); 0, n_frames otherwise
         bool operator==(const GraphKey &o) const {
             return px == o.px && n_frames == o.n_frames && format == o.format && row_stride == o.row_stride && frame_stride == o.frame_stride &&
-                   kp == o.kp && kp_cap == o.kp_cap && desc == o.desc && desc_cap == o.desc_cap && counts == o.counts && totals == o.totals && st == o.st;
+                   kp == o.kp && kp_cap == o.kp_cap && desc == o.desc && desc_cap == o.desc_cap && counts == o.counts && totals == o.totals && st == o.st &&
+                   frame_base == o.frame_base && total_frames == o.total_frames;
         }
     };
     // Captured launch sequences, most recently used last; up to GCACHE_MAX call signatures per context, the least recently
@@ -260,7 +283,9 @@ static void free_ctx(siftmi_ctx *c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->oct_stream[i]) (void)hipStreamDestroy(c->oct_stream[i]);
     }
-    c->h_kp.release(); c->h_desc.release();
+    c->h_kp.release(); c->h_desc.release(); c->h_sub.release();
+    for (hipEvent_t e : c->ev_sub) if (e) (void)hipEventDestroy(e);
+    if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
     for (int i = 0; i < 2; i++) {
         if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
         if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
@@ -365,7 +390,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
 
     hipError_t e = hipSetDevice(hip_device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = create_copy_stream(&c->copy_stream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
     for (int i = 0; i < 2; i++) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
@@ -487,6 +512,15 @@ static bool uses_march(const siftmi_ctx *c, int w, int h, int nf) {
     return total >= c->march_min_blocks;
 }
 
+// EXPERIMENT: unused dynamic LDS added to every ring launch (fewer resident ring workgroups per CU, so that another stream's
+// keypoint kernels find LDS and wave slots beside them)
+static size_t ring_pad_lds() {
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_RING_PAD_LDS")) return (size_t)atoll(e);
+#endif
+    return 0;
+}
+
 template <int R, bool SEED, bool DEC>
 static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src, float *dst, int w, int h, int nf,
                                  const TapWeights &wt, const SeedSource &seed, const Decimate &dec, const Activity &act) {
@@ -501,10 +535,10 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
             march = true;
             dim3 grid(((total + 7) / 8) * 8, 1, 1);
             if (act.dst)
-                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, true>), grid, dim3(Gr::NTHR), Gr::lds_bytes_act, st, src, dst, w, h,
+                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, true>), grid, dim3(Gr::NTHR), Gr::lds_bytes_act + ring_pad_lds(), st, src, dst, w, h,
                                    c->frame_stride, c->frame_stride, wt, nf, chr, dec, act, seed);
             else
-                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, false>), grid, dim3(Gr::NTHR), Gr::lds_bytes, st, src, dst, w, h, c->frame_stride,
+                hipLaunchKernelGGL((blur_ring_kernel<R, 4, 32, DEC, false>), grid, dim3(Gr::NTHR), Gr::lds_bytes + ring_pad_lds(), st, src, dst, w, h, c->frame_stride,
                                    c->frame_stride, wt, nf, chr, dec, act, seed);
         }
     } else if constexpr (R >= 4 && R <= 6) {
@@ -960,6 +994,76 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
     return SIFTMI_OK;
 }
 
+// Replays the captured launch sequence of call signature `key` on `st`, capturing it first on the signature's SECOND sighting (a
+// caller that passes fresh buffers with every call would otherwise pay capture + instantiation each time and fill the cache with
+// graphs that are never replayed); *launched = false: nothing was enqueued (graphs off, first sighting, cache full on a runtime
+// that cannot destroy graphs, capture failed) and the caller issues direct launches.  `enqueue(fork)` issues the launch sequence.
+template <typename Enqueue>
+static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::GraphKey &key, Enqueue enqueue, bool *launched) {
+    *launched = false;
+    const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && getenv("SIFTMI_NO_GRAPH") == nullptr;
+    if (!want_graph) return SIFTMI_OK;
+    int rc = SIFTMI_OK;
+    hipGraphExec_t exec = nullptr;
+    bool seen = false;
+    for (const auto &k : c->gseen) seen = seen || k == key;
+    if (!seen) {
+        if (c->gseen.size() >= 16) c->gseen.erase(c->gseen.begin());
+        c->gseen.push_back(key);
+    }
+    for (size_t i = 0; i < c->gcache.size(); i++)
+        if (c->gcache[i].key == key) {                       // hit: move to the back (most recently used)
+            const siftmi_ctx::GraphEntry hit = c->gcache[i];
+            c->gcache.erase(c->gcache.begin() + (long)i);
+            c->gcache.push_back(hit);
+            exec = hit.exec;
+            // a replay does not run the host code that sets it; later sub-batches of one call can only take it away
+            c->raw_exact = key.frame_base == 0 ? hit.raw_exact : (c->raw_exact && hit.raw_exact);
+            break;
+        }
+    // A full cache evicts its least recently used signature -- but only on a runtime whose hipGraphExecDestroy is safe
+    // (graph_destroy_safe): on an older one an evicted graph can only be abandoned (a few hundred kB each), so a long-running
+    // caller whose buffers keep changing would leak without bound.  There the cache simply stops growing and new signatures
+    // run as direct launches (round 2's behaviour).
+    bool may_capture = seen;
+    if (!exec && seen && c->gcache.size() >= graph_cache_max()) {
+        if (graph_destroy_safe()) {
+            (void)hipDeviceSynchronize();                  // it may still be running
+            retire_exec(c->gcache.front().exec);
+            c->gcache.erase(c->gcache.begin());
+        } else {
+            may_capture = false;
+        }
+    }
+    if (!exec && may_capture) {
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rc = enqueue(fork_chains(c));
+            e = hipStreamEndCapture(st, &graph);
+            if (rc == SIFTMI_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            else if (rc == SIFTMI_OK && e == hipSuccess) e = hipErrorUnknown;
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (rc != SIFTMI_OK || e != hipSuccess || !exec) {
+            (void)hipGetLastError();
+            exec = nullptr;
+            c->graph_failed = true;          // fall through to direct launches, now and later
+        } else {
+            // what run_dense_detect decided for THIS launch sequence: raw extrema counts are exact unless an octave's scan skips rows
+            bool seq_exact = true;
+            for (int o = 0; o < c->n_oct; o++) seq_exact = seq_exact && !c->act_valid[o];
+            c->gcache.push_back(siftmi_ctx::GraphEntry{key, exec, seq_exact});
+        }
+    }
+    if (exec) {
+        StageRange rg("siftmi graph replay (detect+describe batch)");
+        HIP_TRY(hipGraphLaunch(exec, st));
+        *launched = true;
+    }
+    return SIFTMI_OK;
+}
+
 extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_frames, const void *d_pixels, int format, size_t row_stride,
                                                    size_t frame_stride, siftmi_keypoint *d_keypoints, int64_t kp_capacity,
                                                    siftmi_descriptor *d_descriptors, int64_t desc_capacity, int32_t *d_counts,
@@ -974,74 +1078,16 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
     if (rc) return rc;
     if ((rc = order_begin(c, st))) return rc;            // after whatever the previous call left running on another stream
     c->stats_on_device = true;
-    const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && getenv("SIFTMI_NO_GRAPH") == nullptr;
-    if (want_graph) {
-        const siftmi_ctx::GraphKey key{d_pixels, n_frames, format, row_stride, frame_stride, d_keypoints, (long long)kp_capacity, d_descriptors,
-                                       (long long)desc_capacity, d_counts, d_totals, st};
-        hipGraphExec_t exec = nullptr;
-        // a signature is captured on its SECOND sighting: a caller that passes fresh buffers with every call would
-        // otherwise pay capture + instantiation each time and fill the cache with graphs that are never replayed
-        bool seen = false;
-        for (const auto &k : c->gseen) seen = seen || k == key;
-        if (!seen) {
-            if (c->gseen.size() >= 16) c->gseen.erase(c->gseen.begin());
-            c->gseen.push_back(key);
-        }
-        for (size_t i = 0; i < c->gcache.size(); i++)
-            if (c->gcache[i].key == key) {                       // hit: move to the back (most recently used)
-                const siftmi_ctx::GraphEntry hit = c->gcache[i];
-                c->gcache.erase(c->gcache.begin() + (long)i);
-                c->gcache.push_back(hit);
-                exec = hit.exec;
-                c->raw_exact = hit.raw_exact;                     // a replay does not run the host code that sets it
-                break;
-            }
-        // A full cache evicts its least recently used signature -- but only on a runtime whose hipGraphExecDestroy is safe
-        // (graph_destroy_safe): on an older one an evicted graph can only be abandoned (a few hundred kB each), so a long-running
-        // caller whose buffers keep changing would leak without bound.  There the cache simply stops growing and new signatures
-        // run as direct launches (round 2's behaviour).
-        bool may_capture = seen;
-        if (!exec && seen && c->gcache.size() >= graph_cache_max()) {
-            if (graph_destroy_safe()) {
-                (void)hipDeviceSynchronize();                  // it may still be running
-                retire_exec(c->gcache.front().exec);
-                c->gcache.erase(c->gcache.begin());
-            } else {
-                may_capture = false;
-            }
-        }
-        if (!exec && may_capture) {
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                const bool fork = fork_chains(c);
-                rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
-                                   (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals, fork);
-                e = hipStreamEndCapture(st, &graph);
-                if (rc == SIFTMI_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                else if (rc == SIFTMI_OK && e == hipSuccess) e = hipErrorUnknown;
-                if (graph) (void)hipGraphDestroy(graph);
-            }
-            if (rc != SIFTMI_OK || e != hipSuccess || !exec) {
-                (void)hipGetLastError();
-                exec = nullptr;
-                c->graph_failed = true;          // fall through to direct launches, now and later
-            } else {
-                c->gcache.push_back(siftmi_ctx::GraphEntry{key, exec, c->raw_exact});
-            }
-        }
-        if (exec) {
-            StageRange rg("siftmi graph replay (detect+describe batch)");
-            HIP_TRY(hipGraphLaunch(exec, st));
-            c->last_sub_frames = std::min(c->B, n_frames - ((n_frames - 1) / c->B) * c->B);
-            c->last_frames = n_frames;
-            c->pyramid_valid = true;
-            return order_end(c, st);
-        }
-    }
-    rc = enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
-                       (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals, false);
-    if (rc) return rc;
+    const siftmi_ctx::GraphKey key{d_pixels, n_frames, format, row_stride, frame_stride, d_keypoints, (long long)kp_capacity, d_descriptors,
+                                   (long long)desc_capacity, d_counts, d_totals, st, 0, n_frames};
+    auto enqueue = [&](bool fork) {
+        return enqueue_batch(c, st, n_frames, d_pixels, format, row_stride, frame_stride, (KeypointRec *)d_keypoints, kp_capacity,
+                             (DescriptorRec *)d_descriptors, desc_capacity, d_counts, d_totals, fork);
+    };
+    bool launched = false;
+    if ((rc = replay_or_capture(c, st, key, enqueue, &launched))) return rc;
+    if (launched) c->last_sub_frames = std::min(c->B, n_frames - ((n_frames - 1) / c->B) * c->B);
+    else if ((rc = enqueue(false))) return rc;
     c->last_frames = n_frames;
     c->pyramid_valid = true;
     return order_end(c, st);
@@ -1148,30 +1194,83 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     c->tstream = st;
     if ((rc = order_begin(c, st))) return rc;
     c->stats_on_device = false;
-    for (int f0 = 0; f0 < n_frames; f0 += c->B) {
-        const int nf = std::min(c->B, n_frames - f0);
+    // Host frames of a call that spans several sub-batches: the kernels of sub-batch i run under the upload of sub-batch i + 1
+    // (stage_input), but nothing runs under the FIRST upload -- so the first sub-batch is a quarter of the lock-step size (its
+    // upload is the only exposed one; frames are independent, so the split changes no result).  Round 4: 64 x 1080p from pinned
+    // memory through 16-frame sub-batches, 4 + 16 + 16 + 16 + 12 instead of 4 x 16.
+    const int first_nf = (!on_device && n_frames > c->B && c->B >= 4) ? c->B / 4 : c->B;
+    const int n_sub = first_nf < c->B ? 1 + (n_frames - first_nf + c->B - 1) / c->B : (n_frames + c->B - 1) / c->B;
+    HIP_TRY(c->h_sub.resize(4 * (size_t)n_sub));
+    HIP_TRY(c->h_kp.resize(1)); HIP_TRY(c->h_desc.resize(1));          // (callers get non-null pointers for empty results too)
+    while ((int)c->ev_sub.size() < n_sub) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_sub.push_back(e);
+    }
+    if (!c->d2h_stream) HIP_TRY(create_copy_stream(&c->d2h_stream));
+    int sub = 0;
+    for (int f0 = 0, nf = 0; f0 < n_frames; f0 += nf, sub++) {
+        nf = std::min(f0 == 0 ? first_nf : c->B, n_frames - f0);
         const void *d_px; size_t d_row, d_frame;
         const unsigned char *src = (const unsigned char *)pixels + (size_t)f0 * frame_stride;
         if ((rc = stage_input(c, nf, src, format, row_stride, frame_stride, on_device, &d_px, &d_row, &d_frame))) return rc;
-        if ((rc = run_dense_detect(c, st, nf, d_px, format, d_row, d_frame, false, f0 == 0))) return rc;
+        // The launch sequence of a sub-batch is captured and replayed like a device-resident call's (round 4: until then this entry
+        // issued ~40 direct launches per sub-batch on one chain): its signature is the staging slot (or the caller's device
+        // frames), the sub-batch's place in the call and the context's own output buffers, so repeated calls of one shape
+        // replay ~5 graphs with the per-octave chains forked.  The staged frames are free again when the whole sequence has run.
+        auto enqueue = [&](bool fork) -> int {
+            int r;
+            if ((r = run_dense_detect(c, st, nf, d_px, format, d_row, d_frame, fork, f0 == 0))) return r;
+            if (!fork) {
+                if ((r = run_refine(c, st, nf))) return r;
+                if ((r = run_describe(c, st, nf))) return r;
+            }
+            return run_pack(c, st, nf, f0, n_frames, c->d_out_kp, c->out_kp_cap, c->d_out_desc, c->out_desc_cap, c->d_out_counts, c->d_stats);
+        };
+        const siftmi_ctx::GraphKey key{d_px, nf, format, d_row, d_frame, c->d_out_kp, c->out_kp_cap, c->d_out_desc, c->out_desc_cap,
+                                       c->d_out_counts, c->d_stats, st, f0, n_frames};
+        bool launched = false;
+        // Frames that are being uploaded: the sub-batch's sequence stays ONE chain.  A forked graph's four octave chains take all
+        // four hardware queues the runtime gives a process by default, the copy stream then shares one with a chain and the upload
+        // of the next sub-batch waits for this one's kernels instead of running under them (measured: 19.5-19.8 ms per 64 x 1080p
+        // call forked, 14.8-16.0 one chain; with the copy streams on hardware queues of their own -- SIFTMI_COPY_STREAM_PRIORITY=1
+        // -- 16.4-16.7 forked).
+        auto enqueue_g = [&](bool fork) { return enqueue(fork && on_device != 0); };
+        if ((rc = replay_or_capture(c, st, key, enqueue_g, &launched))) return rc;
+        if (!launched && (rc = enqueue(false))) return rc;
         if ((rc = input_consumed(c, on_device))) return rc;
-        if ((rc = run_refine(c, st, nf))) return rc;
-        if ((rc = run_describe(c, st, nf))) return rc;
-        if ((rc = run_pack(c, st, nf, f0, n_frames, c->d_out_kp, c->out_kp_cap, c->d_out_desc, c->out_desc_cap, c->d_out_counts, c->d_stats)))
-            return rc;
+        // the running totals after this sub-batch: its packed records are final from here on
+        HIP_TRY(hipMemcpyAsync(c->h_sub.data() + 4 * sub, c->d_state, sizeof(PackState), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->ev_sub[(size_t)sub], st));
         c->last_sub_frames = nf;
     }
-    PackState ps;
-    HIP_TRY(hipMemcpyAsync(&ps, c->d_state, sizeof(ps), hipMemcpyDeviceToHost, st));
     const size_t ng = (size_t)n_frames * c->n_oct;
     c->h_counts.resize(2 * ng); c->h_stats.resize(5 * ng);
     HIP_TRY(hipMemcpyAsync(c->h_counts.data(), c->d_out_counts, 2 * ng * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(c->h_stats.data(), c->d_stats, 5 * ng * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(c->h_kp.resize((size_t)std::max(ps.total_kp, 1))); HIP_TRY(c->h_desc.resize((size_t)std::max(ps.total_desc, 1)));
-    if (ps.total_kp) HIP_TRY(hipMemcpyAsync(c->h_kp.data(), c->d_out_kp, (size_t)ps.total_kp * sizeof(KeypointRec), hipMemcpyDeviceToHost, st));
-    if (ps.total_desc) HIP_TRY(hipMemcpyAsync(c->h_desc.data(), c->d_out_desc, (size_t)ps.total_desc * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // Copy-back.  The packed records of sub-batch i go to the page-locked result buffers as soon as its totals are on the host,
+    // on a third stream, while the later sub-batches still compute -- as long as the buffers (sized by earlier calls, + 50 %)
+    // hold them; otherwise (first call, a much denser batch) everything is copied after the last sub-batch, as before round 4.
+    size_t done_k = 0, done_d = 0;
+    bool incremental = true;
+    for (int i = 0; i < n_sub; i++) {
+        HIP_TRY(hipEventSynchronize(c->ev_sub[(size_t)i]));
+        const size_t tk = (size_t)std::max(c->h_sub.data()[4 * i], 0), td = (size_t)std::max(c->h_sub.data()[4 * i + 1], 0);
+        if (!incremental || tk > c->h_kp.cap || td > c->h_desc.cap) { incremental = false; continue; }
+        if (tk > done_k) HIP_TRY(hipMemcpyAsync(c->h_kp.data() + done_k, c->d_out_kp + done_k, (tk - done_k) * sizeof(KeypointRec), hipMemcpyDeviceToHost, c->d2h_stream));
+        if (td > done_d) HIP_TRY(hipMemcpyAsync(c->h_desc.data() + done_d, c->d_out_desc + done_d, (td - done_d) * sizeof(DescriptorRec), hipMemcpyDeviceToHost, c->d2h_stream));
+        done_k = std::max(done_k, tk); done_d = std::max(done_d, td);
+    }
+    PackState ps;
+    memcpy(&ps, c->h_sub.data() + 4 * (n_sub - 1), sizeof(ps));
+    HIP_TRY(hipStreamSynchronize(st));                       // counts and statistics
+    HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+    if (!incremental) {
+        HIP_TRY(c->h_kp.resize((size_t)std::max(ps.total_kp, 1))); HIP_TRY(c->h_desc.resize((size_t)std::max(ps.total_desc, 1)));
+        if (ps.total_kp) HIP_TRY(hipMemcpyAsync(c->h_kp.data(), c->d_out_kp, (size_t)ps.total_kp * sizeof(KeypointRec), hipMemcpyDeviceToHost, st));
+        if (ps.total_desc) HIP_TRY(hipMemcpyAsync(c->h_desc.data(), c->d_out_desc, (size_t)ps.total_desc * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     t_collect(c);
     c->last_frames = n_frames;
     c->pyramid_valid = true;

@@ -156,8 +156,8 @@ extern "C" int siftmi_stream_create(siftmi_ctx *ctx, const siftmi_stream_config 
         e = hipStreamCreateWithFlags(&s->launch[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_producer[i], hipEventDisableTiming);
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->d2h_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = create_copy_stream(&s->copy_stream);          // own hardware queues: see create_copy_stream
+    if (e == hipSuccess) e = create_copy_stream(&s->d2h_stream);
     s->sets.resize((size_t)s->n_sets);
     const size_t n_counts = 2 * (size_t)s->F * s->n_oct;
     for (auto &rs : s->sets) {
