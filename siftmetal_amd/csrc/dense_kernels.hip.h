@@ -485,7 +485,7 @@ struct RingGeom {
     // staged halo: 8 or 16 columns per side, so that a step's S new rows are a whole number of float4 (+ one float2)
     // per lane -- every lane issues the same loads, none masked (see the note on s_waitcnt at the kernel)
     static constexpr int RP = R <= 8 ? 8 : 16;
-    static constexpr int TW = 128, S = S_, NTHR = 256, NR = 2 * S_, RB = S_ / 4;
+    static constexpr int TW = 128, S = S_, NTHR = 8 * S_, NR = 2 * S_, RB = 8;       // S = 32: 4 wavefronts; S = 64 (experiment): 8, half the barriers per row
     static constexpr int LW = TW + 2 * RP, NT = 2 * R + 1;
     static constexpr int V = LW / 4;                                    // float4 per staged row
     static constexpr int NPF4 = LW / 32;                                // 8 lanes per row: whole float4 per lane ...
@@ -546,7 +546,7 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 // the other wavefronts' horizontal passes do not speed up beside the MFMAs.
 template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12),
           bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */, int VM = 0>
-__global__ __launch_bounds__(256, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+__global__ __launch_bounds__(8 * S_, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                              int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
                                                              SeedSource seed) {

@@ -9,6 +9,7 @@
 #include <vector>
 #include "dense_kernels.hip.h"
 #include "blur_ws.hip.h"
+#include "blur_dma.hip.h"
 using namespace siftmi;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -140,6 +141,20 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("ring WS rolemap=" #MAP_ " rows/chunk=" #CHR_, c, R, [&] { hipLaunchKernelGGL((blur_ring_wsx_kernel<R, MAP_>), grid, dim3(256), 64 * 160 * 4, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_); }); }
         VWSM(256, 1) VWSM(256, 2) VWSM(512, 1) VWSM(512, 2)
+        // round 4 experiment: S = 64 -- 64-row steps, a 128-row ring, 512 threads (8 wavefronts), two workgroups per CU:
+        // half the barriers per output row at the same wavefronts per CU
+#define VR64(CHR_, MINW_, H8_) { using G = RingGeom<R, 64>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        auto kfn = blur_ring_kernel<R, MINW_, 64, false, false, 0, -1, H8_, false>; \
+        CHECK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes)); \
+        run_variant("ring S=64 (512 threads, 128-row ring) rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_, c, R, [&] { hipLaunchKernelGGL(kfn, grid, dim3(512), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
+        VR64(256, 4, (R <= 12)) VR64(512, 4, (R <= 12)) VR64(256, 4, true) VR64(256, 2, (R <= 12))
+        // round 4 experiment: LDS-DMA staging on a five-segment ring (blur_dma.hip.h), plain and with 8 outputs per lane in the horizontal pass
+#define VDMA(CHR_, H8_) { const int tx = c.w / 128, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        run_variant("ring DMA (LDS-DMA staging, 5 x 16-row segments, 2 H + 2 V waves) H8=" #H8_ " rows/chunk=" #CHR_, c, R, [&] { hipLaunchKernelGGL((blur_ring_dma_kernel<R, H8_>), grid, dim3(256), 80 * 160 * 4, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_); }); }
+        VDMA(256, false) VDMA(256, true) VDMA(512, false) VDMA(512, true)
         if constexpr (R >= 9) {     // the shipping wave-specialised kernel (dense_kernels.hip.h), without and with the activity flags
 #define VWSP(CHR_, ACT_) { using Gw = RingWsGeom<R>; const int tx = (c.w + 127) / 128, nch = (c.h + CHR_ - 1) / CHR_; \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
