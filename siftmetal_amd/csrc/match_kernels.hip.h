@@ -41,13 +41,36 @@ __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdg
 // (half 0 before half 1 inside a block, target splits across blockIdx.y in match_finalize_kernel).
 // The scan costs 16 mad + 8 min3 + 1 compare per 32x32 tile; the ordered 16-step update only runs when some
 // lane's tile minimum beats its best (O(log n) times per source).
+//
+// Round 4: chunks start from a BOUND instead of from "no best".  A chunk that restarts at "no best" sets a record in about
+// ln(chunk) of its tiles per lane, and a wavefront takes the 16-step ordered update when ANY of its 64 lanes does -- 40-55 % of
+// all tiles at the split sizes that fill the chip, the largest single cost of the kernel.  But a target can only enter the
+// reference's result (as the best, or as the `second` = the running best just before the last improvement) if it beats the running
+// best at its position, and the minimum over ANY earlier targets is an upper bound on that.  So every block whose chunk does not
+// start at target 0 first runs the first `prefix_len` targets through the MFMA + max screen alone (no ordered update: + prefix_len /
+// split_len of matrix work) and starts its chunk with best = that bound: tiles without a key below the bound are screened out, and
+// the first improvement of a chunk records the bound as its `second`, which the ordered combine (min with the running best, which is
+// <= the bound) treats exactly like "none".  A chunk that never improves reports "none".  Same results, bit for bit
+// (tests/test_gpu_parity.py::test_match_*); the ordered path is then taken on ~1024 / (targets before the tile) of the tiles.
 // =====================================================================================================
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+#ifdef MM_COUNT_SLOW
+__device__ unsigned long long mm_slow_count;               // tools/ubench: (wavefront, tile, source tile) triples that took the ordered update
+#endif
 
-constexpr int MM_NB = 4;                                   // source tiles (of 32) per wave
-constexpr int MM_TT = 2;                                   // target tiles (of 32) staged per barrier
+#ifndef MM_NB_DEF                                          // (tools/ubench/match_variants.hip builds other shapes)
+#define MM_NB_DEF 4
+#endif
+#ifndef MM_TT_DEF
+#define MM_TT_DEF 2
+#endif
+#ifndef MM_WAVES_DEF
+#define MM_WAVES_DEF 2
+#endif
+constexpr int MM_NB = MM_NB_DEF;                           // source tiles (of 32) per wave
+constexpr int MM_TT = MM_TT_DEF;                           // target tiles (of 32) staged per barrier
 constexpr int MM_SRC_PER_BLOCK = 32 * MM_NB * 4;           // 512
 constexpr int MM_SPLIT_QUANTUM = 32 * MM_TT;               // a split's target range is a multiple of this
 constexpr int MM_ROW = 144;                                // LDS row stride in bytes: 128 + 16 -> conflict-free ds_read_b128
@@ -73,10 +96,11 @@ __global__ __launch_bounds__(256) void match_prep_kernel(const DescriptorRec *__
 
 // amdgpu_waves_per_eu(2): caps the kernel at 256 VGPRs, which makes the compiler keep the MFMA results in VGPRs
 // (no v_accvgpr_read per element in the scan).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM_WAVES_DEF, MM_WAVES_DEF)))
 void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int *__restrict__ tgt_packed,
                        const int *__restrict__ tgt_norm, int n_tgt, int split_len /* multiple of MM_SPLIT_QUANTUM */,
-                       int4 *__restrict__ part /* [gridDim.y][n_src]: best, idx, second */) {
+                       int4 *__restrict__ part /* [gridDim.y][n_src]: best, idx, second */,
+                       int prefix_len /* 0, or a multiple of MM_SPLIT_QUANTUM <= split_len: targets screened for the chunks' starting bound */) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][MM_TT][32 * MM_ROW];
     __shared__ __attribute__((aligned(16))) int lds_c[2][MM_TT][32];    // C-in of the MFMA chain: -(|b'|^2 >> 1)
     __shared__ __attribute__((aligned(16))) int lds_n[2][MM_TT][32];    // |b'|^2 (only read on the ordered-update path)
@@ -94,7 +118,7 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
     }
     // staging role of this thread: tile row r (MFMA row), 16-byte piece p, of each of the MM_TT tiles
     const int r = tid >> 3, p = tid & 7, hr = (r >> 2) & 1, pos = (r >> 3) * 4 + (r & 3);
-    const int st_base = t_lo + hr * half_len + pos, st_end = hr ? t_hi : min(t_hi, t_lo + half_len);
+    int st_base = t_lo + hr * half_len + pos, st_end = hr ? t_hi : min(t_hi, t_lo + half_len);
     i32x4 pre_v[MM_TT]; int pre_n[MM_TT];
     auto prefetch = [&](int it) {
 #pragma unroll
@@ -123,18 +147,96 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 #pragma unroll
     for (int nb = 0; nb < MM_NB; nb++) { best[nb] = MM_NONE; idx[nb] = -1; second[nb] = MM_NONE; thr[nb] = (-MM_NONE) >> 1; }
 
+    // ---- the starting bound of a chunk that does not begin at target 0: max accumulator over the first prefix_len targets (both
+    // lane halves: the prefix is walked as a little chunk of its own, same staging roles), i.e. min key <= 1 - 2 max
+    if (prefix_len > 0 && t_lo > 0) {
+        const int p_half = prefix_len >> 1, p_iter = p_half / (16 * MM_TT);
+        st_base = hr * p_half + pos; st_end = hr ? min(n_tgt, prefix_len) : min(n_tgt, p_half);
+        int amax[MM_NB];
+#pragma unroll
+        for (int nb = 0; nb < MM_NB; nb++) amax[nb] = (int)0x80000000;
+        prefetch(0); stage(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        for (int it = 0; it < p_iter; it++) {
+            const int cur = it & 1;
+            if (it + 1 < p_iter) prefetch(it + 1);
+#pragma unroll
+            for (int j = 0; j < MM_TT; j++) {
+                i32x4 a[4];
+                i32x16 cin;
+#pragma unroll
+                for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const i32x4 *>(&lds_a[cur][j][c * MM_ROW + m * 32 + h * 16]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
+                    cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
+                }
+#pragma unroll
+                for (int nb0 = 0; nb0 < MM_NB; nb0 += 2) {
+                    i32x16 acc[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], cin, 0, 0, 0);
+#pragma unroll
+                        for (int m = 1; m < 4; m++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[nb0 + u][m], acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        int tmax = acc[u][0];
+#pragma unroll
+                        for (int i = 1; i < 16; i++) tmax = max(tmax, acc[u][i]);
+                        amax[nb0 + u] = max(amax[nb0 + u], tmax);
+                    }
+                }
+            }
+            if (it + 1 < p_iter) stage(cur ^ 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int nb = 0; nb < MM_NB; nb++) {
+            const int am = max(amax[nb], __shfl_xor(amax[nb], 32, 64));
+            // padding rows carry acc ~ -2^25: a prefix of real targets always has am far above that; guard the arithmetic anyway
+            if (am > -(1 << 24)) { best[nb] = 1 - 2 * am; thr[nb] = (-best[nb]) >> 1; }
+        }
+        st_base = t_lo + hr * half_len + pos; st_end = hr ? t_hi : min(t_hi, t_lo + half_len);
+    }
+    // ---- and whatever the blocks of EARLIER splits (targets before this chunk) have already published: their chunk's best key per
+    // source (`part` is cleared to "none" before the launch, a finished block stores its records write-through).  Blocks are
+    // dispatched roughly in split order, so a late split usually finds most of its predecessors done.  Any value read is the key of a
+    // real earlier target or "none" -- a valid bound whatever the timing, so the RESULT does not depend on it, only the number of
+    // ordered updates does.
+    if (prefix_len > 0 && blockIdx.y > 0) {
+#pragma unroll
+        for (int nb = 0; nb < MM_NB; nb++) {
+            const int s = min(s0 + nb * 32 + c, n_src - 1);
+            int pub = MM_NONE;
+            for (int y = 0; y < (int)blockIdx.y; y++)
+                pub = min(pub, __hip_atomic_load(reinterpret_cast<const int *>(part + (long long)y * n_src + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (pub < best[nb] && pub > -MM_PAD_LIMIT) { best[nb] = pub; thr[nb] = (-best[nb]) >> 1; }
+        }
+    }
+
     if (n_iter > 0) { prefetch(0); stage(0); }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the source fragments have landed, so the loop's only VMEM waits are its prefetches
     __syncthreads();
+    // Software pipeline inside an iteration (round 4).  The work of an iteration is G = MM_TT x MM_NB / 2 groups of 8 MFMAs (one
+    // target tile x two source tiles) each followed by the max screen of its 2 x 16 accumulators.  Round 1 ran "8 MFMAs, then their
+    // screen" group by group: a wavefront's matrix pipe idled through every screen and every wait for the last MFMA's result, and the
+    // LDS reads of a tile's A fragments sat in front of its first MFMA (PMC: matrix pipe 43 % busy at two wavefronts per SIMD).  Now
+    // the MFMAs of group g + 1 are ISSUED before group g is screened (two accumulator sets), and the A fragments / chain inputs of
+    // tile j + 1 are read from LDS while tile j's last group runs (two fragment sets): the screen's ~40 vector instructions and the
+    // LDS latency fall into the shadow of 256 cycles of MFMAs.
+    constexpr int PAIRS = MM_NB / 2, G = MM_TT * PAIRS;
+    static_assert(MM_NB % 2 == 0, "source tiles are processed in pairs");
     for (int it = 0; it < n_iter; it++) {
         const int cur = it & 1;
 #ifndef MM_VARIANT_NO_LOAD
         if (it + 1 < n_iter) prefetch(it + 1);
 #endif
-#pragma unroll
-        for (int j = 0; j < MM_TT; j++) {
-            i32x4 a[4];
-            i32x16 cin;
+        i32x4 af[2][4];
+        i32x16 cinf[2];
+        auto load_frags = [&](int j, i32x4 (&a)[4], i32x16 &cin) {
 #pragma unroll
             for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const i32x4 *>(&lds_a[cur][j][c * MM_ROW + m * 32 + h * 16]);
 #pragma unroll
@@ -142,41 +244,57 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
                 const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
                 cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
             }
+        };
+        auto issue = [&](const i32x4 (&a)[4], const i32x16 &cin, int nb0, i32x16 (&acc)[2]) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], cin, 0, 0, 0);
+#pragma unroll
+                for (int m = 1; m < 4; m++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[nb0 + u][m], acc[u], 0, 0, 0);
+            }
+        };
+        auto screen = [&](const i32x16 (&acc)[2], int nb0, int j) {
             const int tbase = t_lo + h * half_len + (it * MM_TT + j) * 16;
 #pragma unroll
-            for (int nb0 = 0; nb0 < MM_NB; nb0 += 2) {       // two independent MFMA chains in flight, scans behind them
-                i32x16 acc[2];
+            for (int u = 0; u < 2; u++) {
+                const int nb = nb0 + u;
+                int tmax = acc[u][0];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], cin, 0, 0, 0);
-#pragma unroll
-                    for (int m = 1; m < 4; m++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[nb0 + u][m], acc[u], 0, 0, 0);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int nb = nb0 + u;
-                    int tmax = acc[u][0];
-#pragma unroll
-                    for (int i = 1; i < 16; i++) tmax = max(tmax, acc[u][i]);
+                for (int i = 1; i < 16; i++) tmax = max(tmax, acc[u][i]);
 #ifdef MM_VARIANT_NO_UPDATE
-                    if (tmax > 0x7ffffff0) best[nb] = tmax;
+                if (tmax > 0x7ffffff0) { best[nb] = tmax; idx[nb] = tbase; }
 #else
-                    if (tmax > thr[nb]) {                    // some lane may improve: ordered update, exactly the reference's scan
-                        int at = -1;
-#pragma unroll
-                        for (int g = 0; g < 4; g++) {
-                            const i32x4 pv = *reinterpret_cast<const i32x4 *>(&lds_n[cur][j][h * 16 + g * 4]);
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const int key = (pv[e] & 1) - 2 * acc[u][g * 4 + e];
-                                if (key < best[nb]) { second[nb] = best[nb]; best[nb] = key; at = g * 4 + e; }
-                            }
-                        }
-                        if (at >= 0) { idx[nb] = tbase + at; thr[nb] = (-best[nb]) >> 1; }
-                    }
+                if (tmax > thr[nb]) {                    // some lane may improve: ordered update, exactly the reference's scan
+#ifdef MM_COUNT_SLOW
+                    if (lane == __builtin_ctzll(__ballot(true))) atomicAdd(&mm_slow_count, 1ull);
 #endif
+                    int at = -1;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const i32x4 pv = *reinterpret_cast<const i32x4 *>(&lds_n[cur][j][h * 16 + g * 4]);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int key = (pv[e] & 1) - 2 * acc[u][g * 4 + e];
+                            if (key < best[nb]) { second[nb] = best[nb]; best[nb] = key; at = g * 4 + e; }
+                        }
+                    }
+                    if (at >= 0) { idx[nb] = tbase + at; thr[nb] = (-best[nb]) >> 1; }
                 }
+#endif
             }
+        };
+        i32x16 acc[2][2];
+        load_frags(0, af[0], cinf[0]);
+        issue(af[0], cinf[0], 0, acc[0]);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int j = g / PAIRS, pr = g % PAIRS;
+            if (pr == 0 && j + 1 < MM_TT) load_frags(j + 1, af[(j + 1) & 1], cinf[(j + 1) & 1]);   // a tile ahead of its first MFMA
+            if (g + 1 < G) {
+                const int jn = (g + 1) / PAIRS, prn = (g + 1) % PAIRS;
+                issue(af[jn & 1], cinf[jn & 1], 2 * prn, acc[(g + 1) & 1]);
+            }
+            screen(acc[g & 1], 2 * pr, j);
         }
 #ifndef MM_VARIANT_NO_LOAD
         if (it + 1 < n_iter) stage(cur ^ 1);
@@ -188,13 +306,17 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
     // padding rows and empty chunks -> none;  then half 0 (earlier chunk) with half 1
 #pragma unroll
     for (int nb = 0; nb < MM_NB; nb++) {
-        if (best[nb] >= MM_PAD_LIMIT) { best[nb] = MM_NONE; idx[nb] = -1; }
+        if (best[nb] >= MM_PAD_LIMIT || idx[nb] < 0) { best[nb] = MM_NONE; idx[nb] = -1; second[nb] = MM_NONE; }   // (idx < 0: never beat its starting bound)
         if (second[nb] >= MM_PAD_LIMIT) second[nb] = MM_NONE;
         const int ob = __shfl_xor(best[nb], 32, 64), oi = __shfl_xor(idx[nb], 32, 64), os = __shfl_xor(second[nb], 32, 64);
         if (h == 0) {
             if (ob < best[nb]) { second[nb] = min(best[nb], os); best[nb] = ob; idx[nb] = oi; }
             const int s = s0 + nb * 32 + c;
-            if (s < n_src) part[(long long)blockIdx.y * n_src + s] = make_int4(best[nb], idx[nb], second[nb], 0);
+            if (s < n_src) {
+                int *q = reinterpret_cast<int *>(part + (long long)blockIdx.y * n_src + s);
+                q[1] = idx[nb]; q[2] = second[nb]; q[3] = 0;
+                __hip_atomic_store(q, best[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through: later splits' blocks read it as a bound
+            }
         }
     }
 }

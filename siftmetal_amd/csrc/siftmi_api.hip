@@ -1456,8 +1456,12 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
     int *tgt_norm = src_norm + n_source;
     hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_source * 32 + 255) / 256)), dim3(256), 0, st, d_src, (int)n_source, src_packed, src_norm);
     hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_target * 32 + 255) / 256)), dim3(256), 0, st, d_tgt, (int)n_target, tgt_packed, tgt_norm);
+    // starting bound of the chunks (match_kernels.hip.h, round 4): the first prefix_len targets, at most an eighth of a split
+    long long prefix_len = std::min<long long>(1024, split_len / 8) / MM_SPLIT_QUANTUM * MM_SPLIT_QUANTUM;
+    if (n_split < 2 || split_len < 4096) prefix_len = 0;     // short chunks: the bound's set-up (a clear of `part`, the prefix tiles) costs what it saves
+    if (prefix_len > 0) HIP_TRY(hipMemsetAsync(part, 0x7f, (size_t)n_split * (size_t)n_source * sizeof(int4), st));   // "none" (0x7f7f7f7f) until a block publishes
     hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, (unsigned)n_split), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
-                       (int)n_target, (int)split_len, part);
+                       (int)n_target, (int)split_len, part, (int)prefix_len);
     hipLaunchKernelGGL(match_finalize_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, part, (int)n_split, src_norm, (int)n_source,
                        absolute_threshold, relative_threshold, c->d_match_out);
     HIP_TRY(hipGetLastError());
