@@ -547,7 +547,7 @@ def main():
         runner.run(d_dense)
         dev_sync()
         dres = runner.results_host()
-        dt_d = timed_steps(lambda: runner.run(d_dense), dev_sync, args.steps, 4)   # warm-up: both contexts capture this input's launch sequence
+        dt_d = timed_steps(lambda: runner.run(d_dense), dev_sync, args.steps, 10)  # warm-up: the density hint settles and both contexts capture this input's (one-chain) launch sequence
         ms_d = dt_d / args.steps * 1e3
         out["config"]["dense"] = {"workload": "%d x 1920x1080 mirror-tiled butterfly frames (SURVEY.md 8d dense variant), resident in HBM" % F,
                                   "ms_per_step": round(ms_d, 4), "Mpixels_per_s": round(F * W * H / ms_d / 1e3, 1),

@@ -183,10 +183,11 @@ struct siftmi_ctx {
         const void *px; int n_frames, format; size_t row_stride, frame_stride; void *kp; long long kp_cap; void *desc; long long desc_cap;
         void *counts, *totals; hipStream_t st;
         int frame_base, total_frames;              // a sub-batch of the host-fed call (frames frame_base ... of total_frames); 0, n_frames otherwise
+        bool fork = false;                         // the captured sequence forks into per-octave chains (fork_chains at capture time)
         bool operator==(const GraphKey &o) const {
             return px == o.px && n_frames == o.n_frames && format == o.format && row_stride == o.row_stride && frame_stride == o.frame_stride &&
                    kp == o.kp && kp_cap == o.kp_cap && desc == o.desc && desc_cap == o.desc_cap && counts == o.counts && totals == o.totals && st == o.st &&
-                   frame_base == o.frame_base && total_frames == o.total_frames;
+                   frame_base == o.frame_base && total_frames == o.total_frames && fork == o.fork;
         }
     };
     // Captured launch sequences, most recently used last; up to GCACHE_MAX call signatures per context, the least recently
@@ -200,6 +201,10 @@ struct siftmi_ctx {
     hipStream_t oct_stream[MAX_OCT] = {};
     hipEvent_t ev_fork[MAX_OCT] = {}, ev_join[MAX_OCT] = {};
     bool fork_ready = false;
+    // Set by the frame stream from the descriptor totals of an earlier step (siftmi_stream_*): frames dense with keypoints run 2-3 %
+    // faster on ONE chain (their keypoint stages are half the step and pair better with the other context's whole pyramid than with
+    // their own octaves' blurs), sparse ones 4 % faster forked.  Only consulted when cfg.graph_fork == 0 (automatic).
+    bool dense_hint = false;
     hipStream_t tstream = nullptr;            // stream the timing events are recorded on
     // timings
     bool timing = false;
@@ -664,7 +669,7 @@ static bool fork_chains(const siftmi_ctx *c) {
     if (const char *e = getenv("SIFTMI_EXP_FORK_PX")) max_px = atoll(e);
 #endif
     if (c->cfg.graph_fork) return c->n_oct > 1 && c->cfg.graph_fork > 0;
-    return c->n_oct > 1 && (long long)c->ow[0] * c->oh[0] <= max_px;
+    return c->n_oct > 1 && (long long)c->ow[0] * c->oh[0] <= max_px && !c->dense_hint;
 }
 
 static float *gauss_ptr(siftmi_ctx *c, int o, int s) {
@@ -999,7 +1004,9 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
 // graphs that are never replayed); *launched = false: nothing was enqueued (graphs off, first sighting, cache full on a runtime
 // that cannot destroy graphs, capture failed) and the caller issues direct launches.  `enqueue(fork)` issues the launch sequence.
 template <typename Enqueue>
-static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::GraphKey &key, Enqueue enqueue, bool *launched) {
+static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::GraphKey &key_in, Enqueue enqueue, bool *launched) {
+    siftmi_ctx::GraphKey key = key_in;
+    key.fork = fork_chains(c);                               // (may change between calls: the stream's density hint)
     *launched = false;
     const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && getenv("SIFTMI_NO_GRAPH") == nullptr;
     if (!want_graph) return SIFTMI_OK;
@@ -1039,7 +1046,7 @@ static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::Gr
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            rc = enqueue(fork_chains(c));
+            rc = enqueue(key.fork);
             e = hipStreamEndCapture(st, &graph);
             if (rc == SIFTMI_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             else if (rc == SIFTMI_OK && e == hipSuccess) e = hipErrorUnknown;

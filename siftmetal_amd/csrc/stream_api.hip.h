@@ -23,6 +23,9 @@ struct StreamResultSet {
     hipEvent_t ev_ready = nullptr;            // the step that wrote this set has finished (launch stream)
     hipEvent_t ev_d2h = nullptr;              // the host copy started at submit time has finished (d2h stream)
     hipEvent_t ev_gather = nullptr;           // the exchange that read this set has finished (gather stream)
+    hipEvent_t ev_tot = nullptr;              // the step's totals have arrived in h_tot (d2h stream): the density hint of later steps
+    int32_t *h_tot = nullptr;                 // pinned {n_kp, n_desc, flags, 0}
+    bool tot_rec = false;
     bool ready_rec = false, d2h_rec = false, gather_rec = false;
     int64_t step = -1;                        // the step this set holds
     int64_t spec_kp = 0, spec_desc = 0;       // records covered by the copy started at submit time
@@ -106,8 +109,9 @@ extern "C" void siftmi_stream_destroy(siftmi_stream *s) {
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (rs.h_meta) (void)hipHostFree(rs.h_meta);
         rs.h_kp.release(); rs.h_desc.release();
-        hipEvent_t evs[] = {rs.ev_ready, rs.ev_d2h, rs.ev_gather};
+        hipEvent_t evs[] = {rs.ev_ready, rs.ev_d2h, rs.ev_gather, rs.ev_tot};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        if (rs.h_tot) (void)hipHostFree(rs.h_tot);
     }
     for (unsigned char *p : s->staging) if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev_uploaded) if (e) (void)hipEventDestroy(e);
@@ -172,6 +176,8 @@ extern "C" int siftmi_stream_create(siftmi_ctx *ctx, const siftmi_stream_config 
         if (e == hipSuccess) e = hipEventCreateWithFlags(&rs.ev_ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&rs.ev_d2h, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&rs.ev_gather, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&rs.ev_tot, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&rs.h_tot, 4 * sizeof(int32_t), hipHostMallocDefault);
     }
     if (rc == SIFTMI_OK && e != hipSuccess) {
         rc = e == hipErrorOutOfMemory ? SIFTMI_E_NOMEM : SIFTMI_E_HIP;
@@ -225,7 +231,19 @@ static int submit_step(siftmi_stream *s, const void *d_pixels, size_t row_stride
     // this step overwrites the set: the exchange and the host copy that read it (n_sets steps ago) must have finished
     if (rs.gather_rec) HIP_TRY(hipStreamWaitEvent(ls, rs.ev_gather, 0));
     if (rs.d2h_rec) HIP_TRY(hipStreamWaitEvent(ls, rs.ev_d2h, 0));
+    if (rs.tot_rec) HIP_TRY(hipStreamWaitEvent(ls, rs.ev_tot, 0));      // (the 16-byte totals copy of the step that last used this set)
     if (uploaded) HIP_TRY(hipStreamWaitEvent(ls, uploaded, 0));
+    // Density hint for the launch graph (siftmi_ctx::dense_hint): the descriptor total of the most recent step whose totals have
+    // reached the host -- no wait, a few steps late at most.  Above ~1e4 descriptors per 1080p frame (4.8e-3 per input pixel) the
+    // one-chain sequence is the faster one (tools/fork_density_sweep.py, bench.py config.dense), below it the forked one.
+    for (int back = 1; back <= s->n_sets && back <= k; back++) {
+        StreamResultSet &prev = s->sets[(size_t)((k - back) % s->n_sets)];
+        if (prev.step != k - back || !prev.tot_rec || hipEventQuery(prev.ev_tot) != hipSuccess) continue;
+        const double per_px = (double)prev.h_tot[1] / ((double)s->F * s->ctx[0]->cfg.width * s->ctx[0]->cfg.height);
+        s->ctx[ci]->dense_hint = per_px > 4.8e-3;
+        break;
+    }
+    (void)hipGetLastError();                                  // (hipEventQuery's hipErrorNotReady is not an error)
     const int rc = siftmi_detect_describe_batch_device(s->ctx[ci], s->F, d_pixels, s->scfg.format, row_stride, frame_stride, (siftmi_keypoint *)rs.d_kp,
                                                        s->kp_cap, (siftmi_descriptor *)rs.d_desc, s->desc_cap, rs.d_counts, rs.d_totals, ls);
     if (rc) return rc;
@@ -241,6 +259,11 @@ static int submit_step(siftmi_stream *s, const void *d_pixels, size_t row_stride
     }
     HIP_TRY(hipEventRecord(rs.ev_ready, ls));
     rs.ready_rec = true;
+    // the step's totals to the host, behind the step, on the copy-back stream: the density hint of the steps after it
+    rs.tot_rec = false;
+    if (hipStreamWaitEvent(s->d2h_stream, rs.ev_ready, 0) == hipSuccess &&
+        hipMemcpyAsync(rs.h_tot, rs.d_totals, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s->d2h_stream) == hipSuccess &&
+        hipEventRecord(rs.ev_tot, s->d2h_stream) == hipSuccess) rs.tot_rec = true;
     if (s->host_reader) {
         s->host_reader = false;
         const int rc2 = start_host_copy(s, rs);
