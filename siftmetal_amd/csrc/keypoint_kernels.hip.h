@@ -792,8 +792,11 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
     const int w = P.w[o], h = P.h[o];
     const float delta = P.delta[o], lambda = prm.lambda_ori;
     const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
-    for (int k = COOP ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wv); k < n; k += COOP ? (int)gridDim.x : (int)(gridDim.x * 4)) {
-        const KeypointRec kp = kps[base + k];
+    const int k_first = COOP ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wv), k_step = COOP ? (int)gridDim.x : (int)(gridDim.x * 4);
+    KeypointRec kp_next = kps[base + min(k_first, max(n - 1, 0))];      // the record of a wave's NEXT keypoint is requested a keypoint ahead
+    for (int k = k_first; k < n; k += k_step) {
+        const KeypointRec kp = kp_next;
+        kp_next = kps[base + min(k + k_step, n - 1)];
         bool reject;
         {   // SIFTOctave.swift:303-329
             const float minX = 1.0f, minY = 1.0f, maxX = (float)(w - 2), maxY = (float)(h - 2);
