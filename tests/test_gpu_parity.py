@@ -216,6 +216,51 @@ def test_batch_equals_single_and_is_deterministic(sm):
     assert kpos == len(a[0]) and dpos == len(a[2]) and dpos > 100
 
 
+def test_host_batch_call_sub_batches_graphs_and_incremental_copy_back(sm):
+    """siftmi_detect_describe_batch on host frames that span several sub-batches (round 4: a small first sub-batch, one captured launch
+    sequence per sub-batch, packed records of finished sub-batches copied back while later ones compute): per frame exactly what a
+    single-frame context returns, on the first call (everything copied at the end: no buffer sizes known), on repeated calls (graphs
+    replayed, incremental copy-back into buffers sized by the call before), after a much denser batch (buffers outgrown: fallback) and
+    after a sparser one; pinned and pageable host memory; the same frames resident in HBM through the same entry."""
+    import ctypes as C
+    from siftmetal_amd import _capi, stream as smstream
+    sparse = np.stack([blob_frame(320, 240, i, n_blobs=25) for i in range(11)])
+    dense = np.stack([blob_frame(320, 240, 40 + i, n_blobs=260) for i in range(11)])
+    e1 = sm.Engine(320, 240, n_octaves=3, max_batch=1)
+
+    def per_frame(frames):
+        ks, ds, kcs, dcs = [], [], [], []
+        for f in frames:
+            k, kc, d, dc = e1.detect_describe_batch(f[None])
+            ks.append(k); ds.append(d); kcs.append(kc[0]); dcs.append(dc[0])
+        return np.concatenate(ks), np.stack(kcs), np.concatenate(ds), np.stack(dcs)
+
+    want = {"sparse": per_frame(sparse), "dense": per_frame(dense)}
+    assert len(want["dense"][0]) > 3 * len(want["sparse"][0]) > 100
+    eng = sm.Engine(320, 240, n_octaves=3, max_batch=4)          # 11 frames -> sub-batches 1 + 4 + 4 + 2
+    pins = {}
+    for name, fr in (("sparse", sparse), ("dense", dense)):
+        pins[name] = sm.pinned_empty(fr.shape, np.uint8)
+        pins[name][...] = fr
+    for name in ("sparse", "sparse", "sparse", "dense", "dense", "sparse", "dense"):
+        for src in (pins[name], {"sparse": sparse, "dense": dense}[name]):       # page-locked, then pageable
+            got = eng.detect_describe_batch(src)
+            for g, w_ in zip(got, want[name]):
+                assert g.tobytes() == w_.tobytes(), name
+    # frames resident in HBM through the same entry (on_device = 1): forked sub-batch graphs
+    dfr = smstream.DeviceFrames(dense)
+    outs = [C.c_void_p() for _ in range(4)]
+    for _ in range(3):
+        _capi.check(eng.L.siftmi_detect_describe_batch(eng.h, 11, dfr.ptr, _capi.FMT_BGRA8, 320 * 4, 320 * 240 * 4, 1, *[C.byref(o) for o in outs]))
+        nk, nd = len(want["dense"][0]), len(want["dense"][2])
+        k = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint8)), shape=(nk * 44,)).view(_capi.keypoint_dtype)
+        d = np.ctypeslib.as_array(C.cast(outs[2], C.POINTER(C.c_uint8)), shape=(nd * 136,)).view(_capi.descriptor_dtype)
+        assert k.tobytes() == want["dense"][0].tobytes() and d.tobytes() == want["dense"][2].tobytes()
+    for p_ in pins.values():
+        sm.pinned_release(p_)
+    eng.close(); e1.close()
+
+
 @pytest.mark.parametrize("mode", ["default", "march_skip"])
 def test_formats_agree(sm, mode):
     """GRAY8, GRAYF32 and BGRA8 inputs of the same picture, through the tile seed kernel (default) and through the marching
