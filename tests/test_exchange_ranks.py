@@ -130,16 +130,15 @@ def check_every_view_equals_every_ranks_own_results(per_rank, world, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("transport", ["fake", "rccl"])
-@pytest.mark.parametrize("world", [2, 3])
-def test_exchange_ranks_jump_on_one_rank_is_regathered(tmp_path, world, transport):
-    """2 and 3 ranks, two steps in flight, sizes from the previous step.  Rank world-1 alone runs its large frame set at step 3
+@pytest.mark.parametrize("world,pipeline,transport", [(2, 2, "fake"), (3, 2, "fake"), (4, 2, "fake"), (2, 1, "fake"), (2, 2, "rccl"), (3, 2, "rccl")])
+def test_exchange_ranks_jump_on_one_rank_is_regathered(tmp_path, world, pipeline, transport):
+    """2, 3 and 4 ranks, two steps in flight (and one: two result sets against the exchange's two gathered sets), sizes from the previous step.  Rank world-1 alone runs its large frame set at step 3
     (> 1.5x the records): every rank's first look at step 3 is cut short (complete = 0) -- all ranks see the same totals and
     take the same decision --, the next gather call repeats that step in full from its intact result set, and every rank's view
     of every step, read one step late, holds every rank's own packed results byte for byte.  regathered_steps == 1."""
     import siftmetal_amd as sm
     steps, K, R = 8, 3, world - 1
-    per_rank, summary = run_ranks(tmp_path, world, "jump:%d:%d" % (K, R), 2, 0, transport, steps)
+    per_rank, summary = run_ranks(tmp_path, world, "jump:%d:%d" % (K, R), pipeline, 0, transport, steps)
     check_every_view_equals_every_ranks_own_results(per_rank, world, steps)
     # the C hosts' own results are the host API's results for the same frames
     eng = sm.Engine(W, H, n_octaves=N_OCT, max_batch=F)
