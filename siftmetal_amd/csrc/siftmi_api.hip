@@ -184,10 +184,11 @@ struct siftmi_ctx {
         void *counts, *totals; hipStream_t st;
         int frame_base, total_frames;              // a sub-batch of the host-fed call (frames frame_base ... of total_frames); 0, n_frames otherwise
         bool fork = false;                         // the captured sequence forks into per-octave chains (fork_chains at capture time)
+        bool dense = false;                        // ... and was captured under the stream's density hint (no activity flags)
         bool operator==(const GraphKey &o) const {
             return px == o.px && n_frames == o.n_frames && format == o.format && row_stride == o.row_stride && frame_stride == o.frame_stride &&
                    kp == o.kp && kp_cap == o.kp_cap && desc == o.desc && desc_cap == o.desc_cap && counts == o.counts && totals == o.totals && st == o.st &&
-                   frame_base == o.frame_base && total_frames == o.total_frames && fork == o.fork;
+                   frame_base == o.frame_base && total_frames == o.total_frames && fork == o.fork && dense == o.dense;
         }
     };
     // Captured launch sequences, most recently used last; up to GCACHE_MAX call signatures per context, the least recently
@@ -776,7 +777,9 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
         hipStream_t next = cur;
         // DoG activity flags for the extrema scan: only when every layer of this octave goes through the marching blur
         const int chain = chain_tile(c, o, nf);
-        c->act_valid[o] = !c->cfg.count_raw_extrema && c->ow[o] >= 3 && c->oh[o] >= 3 &&
+        // (dense_hint, set by the frame stream from earlier steps' descriptor totals: on frames that are texture throughout every row
+        // is active, the flags skip nothing and only cost the three layers that write them ~11 % each: off)
+        c->act_valid[o] = !c->cfg.count_raw_extrema && !c->dense_hint && c->ow[o] >= 3 && c->oh[o] >= 3 &&
                           (uses_march(c, c->ow[o], c->oh[o], nf) || (!chain && tile_flags(c, o, nf)));
         if (o == 0 && first_of_call) c->raw_exact = true;
         if (c->act_valid[o]) c->raw_exact = false;
@@ -1007,6 +1010,7 @@ template <typename Enqueue>
 static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::GraphKey &key_in, Enqueue enqueue, bool *launched) {
     siftmi_ctx::GraphKey key = key_in;
     key.fork = fork_chains(c);                               // (may change between calls: the stream's density hint)
+    key.dense = c->dense_hint;
     *launched = false;
     const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && getenv("SIFTMI_NO_GRAPH") == nullptr;
     if (!want_graph) return SIFTMI_OK;
