@@ -535,7 +535,15 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
     // the FMA phases); it needs enough strips x chunks to fill the chip, so small octaves keep the tile kernel.
     using Gr = RingGeom<R>;
     if constexpr (!SEED) {
-        const int chr = march_chunk_rows(h);
+        int chr = march_chunk_rows(h);
+        // The FMA-bound radii pay their chunk prologue (2R rows loaded and blurred horizontally for nothing: 10 % of a 256-row chunk at
+        // R = 13) in the resource they are short of, the memory-bound ones prefer many short chunks: per radius, where the grid still
+        // covers the chip at least twice (round 4, tools/chunk_probe.py, 64 x 1080p: octave 0 R = 10 / 13 936 / 944 -> 895 / 920 us
+        // with 544-row chunks, R = 5 / 7 / 8 792 / 817 / 921 -> 819 / 840 / 948; octave 1 R = 10 / 13 262 / 250 -> 244 / 241 us).
+        if (R >= 9) {
+            const long long total_long = (long long)((w + Gr::TW - 1) / Gr::TW) * ((h + 543) / 544) * nf;
+            if (total_long >= 1536 && getenv("SIFTMI_EXP_CHUNK_BIG") == nullptr && getenv("SIFTMI_EXP_CHUNK_SMALL") == nullptr) chr = 544;
+        }
         const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
         if (uses_march(c, w, h, nf)) {
             march = true;
@@ -550,7 +558,11 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
     } else if constexpr (R >= 4 && R <= 6) {
         // the seed layer in marching form (instantiated for the radii around the default schedule's 5; other sigma
         // settings keep the tile kernel): longer chunks, because its prologue runs the luma / upscale expansion twice
-        const int chr = 256;
+        // (round 4, 64 x 1080p: 128 / 192 / 256 / 384 / 544 / 1088 / 2176-row chunks 0.739 / 0.724 / 0.671-0.688 / 0.655 / 0.659 / 0.651 / 0.685 ms)
+        int chr = h >= 1600 ? 544 : 256;
+#ifdef SIFTMI_EXPERIMENT
+        if (const char *e = getenv("SIFTMI_EXP_SEED_CHUNK")) chr = atoi(e);
+#endif
         const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
         if (uses_march(c, w, h, nf)) {
             march = true;
