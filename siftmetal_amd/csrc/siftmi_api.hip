@@ -1232,11 +1232,20 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     }
     if (!c->d2h_stream) HIP_TRY(create_copy_stream(&c->d2h_stream));
     int sub = 0;
+#ifdef SIFTMI_EXPERIMENT
+    static const bool tl_on = getenv("SIFTMI_EXP_TIMELINE") != nullptr;
+    std::vector<hipEvent_t> tl_h2d, tl_comp;
+    hipEvent_t tl_t0 = nullptr;
+    if (tl_on) { (void)hipEventCreate(&tl_t0); (void)hipEventRecord(tl_t0, st); }
+#endif
     for (int f0 = 0, nf = 0; f0 < n_frames; f0 += nf, sub++) {
         nf = std::min(f0 == 0 ? first_nf : c->B, n_frames - f0);
         const void *d_px; size_t d_row, d_frame;
         const unsigned char *src = (const unsigned char *)pixels + (size_t)f0 * frame_stride;
         if ((rc = stage_input(c, nf, src, format, row_stride, frame_stride, on_device, &d_px, &d_row, &d_frame))) return rc;
+#ifdef SIFTMI_EXPERIMENT
+        if (tl_on && !on_device) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->copy_stream); tl_h2d.push_back(e); }
+#endif
         // The launch sequence of a sub-batch is captured and replayed like a device-resident call's (round 4: until then this entry
         // issued ~40 direct launches per sub-batch on one chain): its signature is the staging slot (or the caller's device
         // frames), the sub-batch's place in the call and the context's own output buffers, so repeated calls of one shape
@@ -1265,6 +1274,9 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
         // the running totals after this sub-batch: its packed records are final from here on
         HIP_TRY(hipMemcpyAsync(c->h_sub.data() + 4 * sub, c->d_state, sizeof(PackState), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(c->ev_sub[(size_t)sub], st));
+#ifdef SIFTMI_EXPERIMENT
+        if (tl_on) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); tl_comp.push_back(e); }
+#endif
         c->last_sub_frames = nf;
     }
     const size_t ng = (size_t)n_frames * c->n_oct;
@@ -1294,6 +1306,22 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
         if (ps.total_desc) HIP_TRY(hipMemcpyAsync(c->h_desc.data(), c->d_out_desc, (size_t)ps.total_desc * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+#ifdef SIFTMI_EXPERIMENT
+    if (tl_on) {
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "timeline (ms after the call's first stream operation): ");
+        for (size_t i = 0; i < tl_comp.size(); i++) {
+            float a = 0, b = 0;
+            if (i < tl_h2d.size()) (void)hipEventElapsedTime(&a, tl_t0, tl_h2d[i]);
+            (void)hipEventElapsedTime(&b, tl_t0, tl_comp[i]);
+            fprintf(stderr, "[sub %zu: upload done %.2f, kernels done %.2f] ", i, a, b);
+        }
+        fprintf(stderr, "\n");
+        for (hipEvent_t e : tl_h2d) (void)hipEventDestroy(e);
+        for (hipEvent_t e : tl_comp) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(tl_t0);
+    }
+#endif
     t_collect(c);
     c->last_frames = n_frames;
     c->pyramid_valid = true;
