@@ -59,12 +59,24 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #ifdef MM_COUNT_SLOW
 __device__ unsigned long long mm_slow_count;               // tools/ubench: (wavefront, tile, source tile) triples that took the ordered update
 #endif
+#ifdef MM_STAMPS
+__device__ unsigned long long mm_stamps[4];                // tools/ubench: wavefront cycles in {prefetch issue, MFMA groups + screens, staging, barrier}
+#define MM_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); mm_acc_[k] += t_ - mm_t_; mm_t_ = t_; } while (0)
+#else
+#define MM_STAMP(k) do {} while (0)
+#endif
 
 #ifndef MM_NB_DEF                                          // (tools/ubench/match_variants.hip builds other shapes)
 #define MM_NB_DEF 4
 #endif
 #ifndef MM_TT_DEF
 #define MM_TT_DEF 2
+#endif
+#ifndef MM_PIPE_DEF                                        // 1: two accumulator/fragment sets, group g + 1 issued before g is screened
+#define MM_PIPE_DEF 1
+#endif
+#ifndef MM_CIN_DEF                                         // 1: -(|b'|^2 >> 1) enters as the MFMA chain's C operand (16 registers per set);
+#define MM_CIN_DEF 1                                       // 0: chains start from 0 and the screen adds it (16 more vector adds per 4 MFMAs)
 #endif
 #ifndef MM_WAVES_DEF
 #define MM_WAVES_DEF 2
@@ -229,32 +241,49 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
     // LDS latency fall into the shadow of 256 cycles of MFMAs.
     constexpr int PAIRS = MM_NB / 2, G = MM_TT * PAIRS;
     static_assert(MM_NB % 2 == 0, "source tiles are processed in pairs");
+#ifdef MM_STAMPS
+    unsigned long long mm_t_, mm_acc_[4] = {0, 0, 0, 0};
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mm_t_)::"memory");
+#endif
     for (int it = 0; it < n_iter; it++) {
         const int cur = it & 1;
 #ifndef MM_VARIANT_NO_LOAD
         if (it + 1 < n_iter) prefetch(it + 1);
 #endif
-        i32x4 af[2][4];
-        i32x16 cinf[2];
+        MM_STAMP(0);
+        constexpr int NSET = MM_PIPE_DEF ? 2 : 1;
+        i32x4 af[NSET][4];
+        i32x16 cinf[NSET];
         auto load_frags = [&](int j, i32x4 (&a)[4], i32x16 &cin) {
 #pragma unroll
             for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const i32x4 *>(&lds_a[cur][j][c * MM_ROW + m * 32 + h * 16]);
+            if (MM_CIN_DEF) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
-                cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
+                for (int q = 0; q < 4; q++) {
+                    const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
+                    cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
+                }
             }
         };
         auto issue = [&](const i32x4 (&a)[4], const i32x16 &cin, int nb0, i32x16 (&acc)[2]) {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], cin, 0, 0, 0);
+                if (MM_CIN_DEF) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], cin, 0, 0, 0);
+                else { const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], zero, 0, 0, 0); }
 #pragma unroll
                 for (int m = 1; m < 4; m++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[nb0 + u][m], acc[u], 0, 0, 0);
             }
         };
-        auto screen = [&](const i32x16 (&acc)[2], int nb0, int j) {
+        auto screen = [&](i32x16 (&acc)[2], int nb0, int j) {
             const int tbase = t_lo + h * half_len + (it * MM_TT + j) * 16;
+            if (!MM_CIN_DEF) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { acc[0][q * 4 + e] += v[e]; acc[1][q * 4 + e] += v[e]; }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int nb = nb0 + u;
@@ -283,26 +312,42 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 #endif
             }
         };
-        i32x16 acc[2][2];
-        load_frags(0, af[0], cinf[0]);
-        issue(af[0], cinf[0], 0, acc[0]);
+        i32x16 acc[NSET][2];
+        if (MM_PIPE_DEF) {
+            load_frags(0, af[0], cinf[0]);
+            issue(af[0], cinf[0], 0, acc[0]);
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int j = g / PAIRS, pr = g % PAIRS;
-            if (pr == 0 && j + 1 < MM_TT) load_frags(j + 1, af[(j + 1) & 1], cinf[(j + 1) & 1]);   // a tile ahead of its first MFMA
-            if (g + 1 < G) {
-                const int jn = (g + 1) / PAIRS, prn = (g + 1) % PAIRS;
-                issue(af[jn & 1], cinf[jn & 1], 2 * prn, acc[(g + 1) & 1]);
+            for (int g = 0; g < G; g++) {
+                const int j = g / PAIRS, pr = g % PAIRS;
+                if (pr == 0 && j + 1 < MM_TT) load_frags(j + 1, af[(j + 1) % NSET], cinf[(j + 1) % NSET]);   // a tile ahead of its first MFMA
+                if (g + 1 < G) {
+                    const int jn = (g + 1) / PAIRS, prn = (g + 1) % PAIRS;
+                    issue(af[jn % NSET], cinf[jn % NSET], 2 * prn, acc[(g + 1) % NSET]);
+                }
+                screen(acc[g % NSET], 2 * pr, j);
             }
-            screen(acc[g & 1], 2 * pr, j);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int j = g / PAIRS, pr = g % PAIRS;
+                if (pr == 0) load_frags(j, af[0], cinf[0]);
+                issue(af[0], cinf[0], 2 * pr, acc[0]);
+                screen(acc[0], 2 * pr, j);
+            }
         }
+        MM_STAMP(1);
 #ifndef MM_VARIANT_NO_LOAD
         if (it + 1 < n_iter) stage(cur ^ 1);
 #endif
+        MM_STAMP(2);
 #ifndef MM_VARIANT_NO_BARRIER
         __syncthreads();
 #endif
+        MM_STAMP(3);
     }
+#ifdef MM_STAMPS
+    if (lane == 0) for (int k = 0; k < 4; k++) atomicAdd(&mm_stamps[k], mm_acc_[k]);
+#endif
     // padding rows and empty chunks -> none;  then half 0 (earlier chunk) with half 1
 #pragma unroll
     for (int nb = 0; nb < MM_NB; nb++) {

@@ -58,6 +58,15 @@ int main(int argc, char **argv) {
       const double tiles = (double)groups * n_split * 4 /*waves*/ * MM_NB * (split_len / 2 / 16);
       printf("ordered updates taken: %llu of %.0f (wavefront, 16-target tile, 32-source tile) triples = %.1f %%\n", v, tiles, 100.0 * v / tiles); }
 #endif
+#ifdef MM_STAMPS
+    { unsigned long long z[4] = {0, 0, 0, 0}, v[4]; hipMemcpyToSymbol(HIP_SYMBOL(mm_stamps), z, 32);
+      if (prefix) hipMemset(part, 0x7f, (size_t)n_split * ns * 16);
+      hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prefix);
+      hipDeviceSynchronize(); hipMemcpyFromSymbol(v, HIP_SYMBOL(mm_stamps), 32);
+      const double iters = (double)groups * n_split * 4 * (split_len / 2 / (16 * MM_TT));
+      printf("stamps, cycles per wavefront-iteration (%d MFMAs = %d matrix-pipe cycles): prefetch issue %.0f, MFMA groups + screens %.0f, staging %.0f, barrier %.0f\n",
+             16 * MM_TT * MM_NB / 4 * 4, 32 * 4 * MM_TT * MM_NB, v[0] / iters, v[1] / iters, v[2] / iters, v[3] / iters); }
+#endif
     const double pairs = (double)ns * nt;
     printf("match_mfma %d x %d, %d groups x %d splits (len %lld), prefix %d: %.3f ms, %.2f Tpairs/s, %.3f PFLOP/s(i8)\n", ns, nt, groups, n_split, split_len, prefix, ms,
            pairs / ms / 1e9, pairs * 256 / ms / 1e12);
