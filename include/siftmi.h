@@ -379,6 +379,10 @@ int siftmi_match_descriptors(siftmi_ctx *ctx, const siftmi_descriptor *source, i
                              const siftmi_descriptor *target, int64_t n_target, int on_device,
                              float absolute_threshold, float relative_threshold,
                              const siftmi_match **matches, int64_t *count);
+/* How siftmi_match_descriptors cuts a problem of this size (no reference counterpart; for tests and tuning): targets per chunk, chunks,
+   and whether the chunks start from a bound (a pre-pass over the first 512 targets + the bests earlier chunks have published)
+   instead of from "no best".  The results do not depend on any of it. */
+int siftmi_match_plan(int64_t n_source, int64_t n_target, int64_t *split_len, int64_t *n_split, int *bounded);
 
 /* SIFTDescriptor.approximateMatch(source:target:absoluteThreshold:relativeThreshold:) (SIFT/SIFTDescriptor.swift:362-417)
    over the reference's ANN trie (Utilities/Trie.swift:76-416): Trie(numberOfBins: 8) keyed by indexKey, radius 10, k 2.

@@ -234,6 +234,12 @@ class Engine:
             return np.zeros(0, _capi.match_dtype)
         return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 12,)).view(_capi.match_dtype).copy()
 
+    def match_plan(self, n_source, n_target):
+        """(targets per chunk, chunks, chunks start from a bound) for a problem of this size (siftmi_match_plan)."""
+        sl, ns, b = C.c_int64(), C.c_int64(), C.c_int()
+        _capi.check(self.L.siftmi_match_plan(n_source, n_target, C.byref(sl), C.byref(ns), C.byref(b)))
+        return sl.value, ns.value, bool(b.value)
+
     def approximate_match(self, source, target, absolute_threshold=300.0, relative_threshold=0.6):
         """SIFTDescriptor.approximateMatch on descriptor records -> match records in source order."""
         a = np.ascontiguousarray(source, dtype=descriptor_dtype)

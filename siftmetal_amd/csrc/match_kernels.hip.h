@@ -46,9 +46,10 @@ __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdg
 // ln(chunk) of its tiles per lane, and a wavefront takes the 16-step ordered update when ANY of its 64 lanes does -- 40-55 % of
 // all tiles at the split sizes that fill the chip, the largest single cost of the kernel.  But a target can only enter the
 // reference's result (as the best, or as the `second` = the running best just before the last improvement) if it beats the running
-// best at its position, and the minimum over ANY earlier targets is an upper bound on that.  So every block whose chunk does not
-// start at target 0 first runs the first `prefix_len` targets through the MFMA + max screen alone (no ordered update: + prefix_len /
-// split_len of matrix work) and starts its chunk with best = that bound: tiles without a key below the bound are screened out, and
+// best at its position, and the minimum over ANY earlier targets is an upper bound on that.  So a short pre-pass (this kernel over
+// the first P = 512 targets alone, one more launch) leaves every source's best key among them, and every block whose chunk does not
+// start at target 0 starts with best = min(that, what earlier splits' blocks have published so far): tiles without a key below the
+// bound are screened out, and
 // the first improvement of a chunk records the bound as its `second`, which the ordered combine (min with the running best, which is
 // <= the bound) treats exactly like "none".  A chunk that never improves reports "none".  Same results, bit for bit
 // (tests/test_gpu_parity.py::test_match_*); the ordered path is then taken on ~1024 / (targets before the tile) of the tiles.
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM_WAVES_DE
 void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int *__restrict__ tgt_packed,
                        const int *__restrict__ tgt_norm, int n_tgt, int split_len /* multiple of MM_SPLIT_QUANTUM */,
                        int4 *__restrict__ part /* [gridDim.y][n_src]: best, idx, second */,
-                       int prefix_len /* 0, or a multiple of MM_SPLIT_QUANTUM <= split_len: targets screened for the chunks' starting bound */) {
+                       const int4 *__restrict__ bound /* or null: [n_src] records of a pre-pass over targets [0, P), P <= split_len */) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][MM_TT][32 * MM_ROW];
     __shared__ __attribute__((aligned(16))) int lds_c[2][MM_TT][32];    // C-in of the MFMA chain: -(|b'|^2 >> 1)
     __shared__ __attribute__((aligned(16))) int lds_n[2][MM_TT][32];    // |b'|^2 (only read on the ordered-update path)
@@ -159,70 +160,18 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 #pragma unroll
     for (int nb = 0; nb < MM_NB; nb++) { best[nb] = MM_NONE; idx[nb] = -1; second[nb] = MM_NONE; thr[nb] = (-MM_NONE) >> 1; }
 
-    // ---- the starting bound of a chunk that does not begin at target 0: max accumulator over the first prefix_len targets (both
-    // lane halves: the prefix is walked as a little chunk of its own, same staging roles), i.e. min key <= 1 - 2 max
-    if (prefix_len > 0 && t_lo > 0) {
-        const int p_half = prefix_len >> 1, p_iter = p_half / (16 * MM_TT);
-        st_base = hr * p_half + pos; st_end = hr ? min(n_tgt, prefix_len) : min(n_tgt, p_half);
-        int amax[MM_NB];
-#pragma unroll
-        for (int nb = 0; nb < MM_NB; nb++) amax[nb] = (int)0x80000000;
-        prefetch(0); stage(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        for (int it = 0; it < p_iter; it++) {
-            const int cur = it & 1;
-            if (it + 1 < p_iter) prefetch(it + 1);
-#pragma unroll
-            for (int j = 0; j < MM_TT; j++) {
-                i32x4 a[4];
-                i32x16 cin;
-#pragma unroll
-                for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const i32x4 *>(&lds_a[cur][j][c * MM_ROW + m * 32 + h * 16]);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
-                    cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
-                }
-#pragma unroll
-                for (int nb0 = 0; nb0 < MM_NB; nb0 += 2) {
-                    i32x16 acc[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[nb0 + u][0], cin, 0, 0, 0);
-#pragma unroll
-                        for (int m = 1; m < 4; m++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[nb0 + u][m], acc[u], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        int tmax = acc[u][0];
-#pragma unroll
-                        for (int i = 1; i < 16; i++) tmax = max(tmax, acc[u][i]);
-                        amax[nb0 + u] = max(amax[nb0 + u], tmax);
-                    }
-                }
-            }
-            if (it + 1 < p_iter) stage(cur ^ 1);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int nb = 0; nb < MM_NB; nb++) {
-            const int am = max(amax[nb], __shfl_xor(amax[nb], 32, 64));
-            // padding rows carry acc ~ -2^25: a prefix of real targets always has am far above that; guard the arithmetic anyway
-            if (am > -(1 << 24)) { best[nb] = 1 - 2 * am; thr[nb] = (-best[nb]) >> 1; }
-        }
-        st_base = t_lo + hr * half_len + pos; st_end = hr ? t_hi : min(t_hi, t_lo + half_len);
-    }
-    // ---- and whatever the blocks of EARLIER splits (targets before this chunk) have already published: their chunk's best key per
+    // ---- the starting bound of a chunk that does not begin at target 0 (round 4): the best key of the pre-pass -- this same kernel
+    // launched over targets [0, P) alone, P <= split_len, its records in `bound` --
+    // and whatever the blocks of EARLIER splits (targets before this chunk) have already published: their chunk's best key per
     // source (`part` is cleared to "none" before the launch, a finished block stores its records write-through).  Blocks are
     // dispatched roughly in split order, so a late split usually finds most of its predecessors done.  Any value read is the key of a
     // real earlier target or "none" -- a valid bound whatever the timing, so the RESULT does not depend on it, only the number of
     // ordered updates does.
-    if (prefix_len > 0 && blockIdx.y > 0) {
+    if (bound != nullptr && blockIdx.y > 0) {
 #pragma unroll
         for (int nb = 0; nb < MM_NB; nb++) {
             const int s = min(s0 + nb * 32 + c, n_src - 1);
-            int pub = MM_NONE;
+            int pub = bound[s].x;
             for (int y = 0; y < (int)blockIdx.y; y++)
                 pub = min(pub, __hip_atomic_load(reinterpret_cast<const int *>(part + (long long)y * n_src + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (pub < best[nb] && pub > -MM_PAD_LIMIT) { best[nb] = pub; thr[nb] = (-best[nb]) >> 1; }

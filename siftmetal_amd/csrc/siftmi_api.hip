@@ -1443,6 +1443,44 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
     return SIFTMI_OK;
 }
 
+// Launch geometry of the brute-force matcher for a problem size (also answered by siftmi_match_plan).
+struct MatchPlan { long long groups, split_len, n_split; bool bounded; };
+static MatchPlan match_plan(long long n_source, long long n_target) {
+    MatchPlan p;
+    p.groups = (n_source + MM_SRC_PER_BLOCK - 1) / MM_SRC_PER_BLOCK;
+    // Target splits: each a contiguous target range (a multiple of the staging quantum).  A CU holds 2 blocks, so 512 run at a time;
+    // blocks take equal time, so pick the split count (around 2048 blocks) whose last round is fullest.
+    const long long groups = p.groups;
+    long long split_len = 0;
+    {
+        const long long quanta = (n_target + MM_SPLIT_QUANTUM - 1) / MM_SPLIT_QUANTUM;
+        long long lo = (1024 + groups - 1) / groups, hi = (3072 + groups - 1) / groups;
+        double best_eff = -1.0;
+        for (long long k = lo; k <= hi; k++) {
+            long long q = (quanta + k - 1) / k;                       // quanta per split
+            if (q < 2) q = 2;
+            const long long ns = (quanta + q - 1) / q, blocks = ns * groups;
+            const double eff = (double)blocks / (double)((blocks + 511) / 512 * 512);
+            if (eff > best_eff + 1e-9) { best_eff = eff; split_len = q * MM_SPLIT_QUANTUM; }
+        }
+    }
+    p.split_len = split_len;
+    p.n_split = (n_target + split_len - 1) / split_len;
+    // chunks start from a bound (match_kernels.hip.h, round 4) when they are long enough for its set-up (a clear of the partial
+    // records, a dependent pre-pass launch) to pay
+    p.bounded = p.n_split >= 2 && split_len >= 4096;
+    return p;
+}
+
+extern "C" int siftmi_match_plan(int64_t n_source, int64_t n_target, int64_t *split_len, int64_t *n_split, int *bounded) {
+    if (n_source <= 0 || n_target <= 0 || n_source > (1ll << 30) || n_target > (1ll << 30)) return set_error(SIFTMI_E_BADARG, "bad argument");
+    const MatchPlan p = match_plan(n_source, n_target);
+    if (split_len) *split_len = p.split_len;
+    if (n_split) *n_split = p.n_split;
+    if (bounded) *bounded = p.bounded ? 1 : 0;
+    return SIFTMI_OK;
+}
+
 // SIFTDescriptor.match (SIFT/SIFTDescriptor.swift:298-361) -- see match_kernels.hip.h
 extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *source, int64_t n_source, const siftmi_descriptor *target,
                                         int64_t n_target, int on_device, float absolute_threshold, float relative_threshold,
@@ -1477,42 +1515,33 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
         HIP_TRY(hipMemcpyAsync(c->d_match_tgt, target, (size_t)n_target * sizeof(DescriptorRec), hipMemcpyHostToDevice, st));
         d_src = c->d_match_src; d_tgt = c->d_match_tgt;
     }
-    // target splits: enough blocks to fill 256 CUs twice over, each split a contiguous target range (multiple of 32)
-    const long long groups = (n_source + MM_SRC_PER_BLOCK - 1) / MM_SRC_PER_BLOCK;
-    // Target splits.  A CU holds 2 blocks, so 512 run at a time; blocks take equal time, so pick the split count (around
-    // 2048 blocks) whose last round is fullest.
-    long long split_len = 0;
-    {
-        const long long quanta = (n_target + MM_SPLIT_QUANTUM - 1) / MM_SPLIT_QUANTUM;
-        long long lo = (1024 + groups - 1) / groups, hi = (3072 + groups - 1) / groups;
-        double best_eff = -1.0;
-        for (long long k = lo; k <= hi; k++) {
-            long long q = (quanta + k - 1) / k;                       // quanta per split
-            if (q < 2) q = 2;
-            const long long ns = (quanta + q - 1) / q, blocks = ns * groups;
-            const double eff = (double)blocks / (double)((blocks + 511) / 512 * 512);
-            if (eff > best_eff + 1e-9) { best_eff = eff; split_len = q * MM_SPLIT_QUANTUM; }
-        }
-    }
-    const long long n_split = (n_target + split_len - 1) / split_len;
+    const MatchPlan plan = match_plan(n_source, n_target);
+    const long long groups = plan.groups, split_len = plan.split_len, n_split = plan.n_split;
     if (n_split > 65535) return set_error(SIFTMI_E_BADARG, "too many target splits");
     // scratch: packed int8 rows + norms for both sides, per-split partial results (one allocation)
-    const long long words = n_source * 33 + n_target * 33 + n_split * n_source * 4 + 64;
+    const long long words = n_source * 33 + n_target * 33 + (n_split + 1) * n_source * 4 + 64;
     if ((rc = grow((void **)&c->d_match_scratch, &c->match_scratch_cap, words, sizeof(int)))) return rc;
     if ((rc = grow((void **)&c->d_match_out, &c->match_out_cap, n_source, sizeof(MatchRec)))) return rc;
     int *src_packed = c->d_match_scratch;                               // 16-byte aligned pieces first
     int *tgt_packed = src_packed + n_source * 32;
     int4 *part = (int4 *)(tgt_packed + n_target * 32);
-    int *src_norm = (int *)(part + n_split * n_source);
+    int4 *bound = part + n_split * n_source;                            // the pre-pass's records
+    int *src_norm = (int *)(bound + n_source);
     int *tgt_norm = src_norm + n_source;
     hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_source * 32 + 255) / 256)), dim3(256), 0, st, d_src, (int)n_source, src_packed, src_norm);
     hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_target * 32 + 255) / 256)), dim3(256), 0, st, d_tgt, (int)n_target, tgt_packed, tgt_norm);
-    // starting bound of the chunks (match_kernels.hip.h, round 4): the first prefix_len targets, at most an eighth of a split
-    long long prefix_len = std::min<long long>(1024, split_len / 8) / MM_SPLIT_QUANTUM * MM_SPLIT_QUANTUM;
-    if (n_split < 2 || split_len < 4096) prefix_len = 0;     // short chunks: the bound's set-up (a clear of `part`, the prefix tiles) costs what it saves
-    if (prefix_len > 0) HIP_TRY(hipMemsetAsync(part, 0x7f, (size_t)n_split * (size_t)n_source * sizeof(int4), st));   // "none" (0x7f7f7f7f) until a block publishes
+    // starting bound of the chunks (match_kernels.hip.h, round 4): a pre-pass over the first 512 targets, then the chunks.  Short
+    // chunks go without: the bound's set-up (a clear of `part`, a dependent launch) costs what it saves there.
+    const long long pre_len = 512;
+    const bool bounded = plan.bounded;
+    static_assert(512 % MM_SPLIT_QUANTUM == 0, "the pre-pass is one split of its own");
+    if (bounded) {
+        HIP_TRY(hipMemsetAsync(part, 0x7f, (size_t)n_split * (size_t)n_source * sizeof(int4), st));   // "none" (0x7f7f7f7f) until a block publishes
+        hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, 1), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
+                           (int)std::min<long long>(n_target, pre_len), (int)pre_len, bound, (const int4 *)nullptr);
+    }
     hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, (unsigned)n_split), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
-                       (int)n_target, (int)split_len, part, (int)prefix_len);
+                       (int)n_target, (int)split_len, part, bounded ? bound : (const int4 *)nullptr);
     hipLaunchKernelGGL(match_finalize_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, part, (int)n_split, src_norm, (int)n_source,
                        absolute_threshold, relative_threshold, c->d_match_out);
     HIP_TRY(hipGetLastError());

@@ -532,6 +532,39 @@ def test_match_random_vs_oracle(sm, n_src, n_tgt):
     assert max(n_found) > 0 or n_src <= 5
 
 
+def test_match_large_bounded_chunks_sampled_sources_vs_oracle(sm):
+    """The size class where chunks start from a bound (pre-pass over the first 512 targets + the published bests of earlier chunks,
+    match_kernels.hip.h round 4).  Sources are independent, so the oracle checks a sample of them over ALL targets, bit-exact in
+    the indices; duplicated targets in different chunks pin the first-occurrence and `second` rules across chunk borders."""
+    from oracle import pyoracle
+    n_src, n_tgt = 32768 + 77, 200000 + 13
+    eng = sm.Engine(64, 64, n_octaves=1)
+    split_len, n_split, bounded = eng.match_plan(n_src, n_tgt)
+    assert bounded and n_split >= 2 and split_len >= 4096, (split_len, n_split, bounded)
+    rng = np.random.default_rng(4242)
+    tgt = _sift_like(rng, n_tgt)
+    # exact duplicates of early targets late in the list (other chunks), and of late targets early
+    dup = rng.integers(0, 3000, 400)
+    tgt[rng.integers(n_tgt - 40000, n_tgt, 400)] = tgt[dup]
+    tgt[rng.integers(600, 3000, 100)] = tgt[rng.integers(n_tgt - 20000, n_tgt, 100)]
+    pick = rng.integers(0, n_tgt, n_src)
+    src = np.clip(tgt[pick] + rng.integers(-12, 13, (n_src, 128)), 0, 255).astype(np.int32)
+    src[::3] = _sift_like(rng, len(src[::3]))
+    src[1:1200:3] = tgt[rng.integers(0, n_tgt, len(src[1:1200:3]))]       # exact copies: distance 0, ties with the duplicates
+    sample = np.sort(np.concatenate([np.arange(0, 1200, 5), rng.choice(n_src, 260, replace=False)]))
+    sample = np.unique(sample)
+    for abs_thr, rel_thr in ((1.176, 0.6), (3.0, 1.01)):
+        got = eng.match(_records(sm, src), _records(sm, tgt), abs_thr, rel_thr)
+        want = pyoracle.match(src[sample], tgt, abs_thr, rel_thr)
+        want["source"] = sample[want["source"]]
+        sel = got[np.isin(got["source"], sample)]
+        _assert_matches_equal(sel, want)
+        assert len(want) > 50
+    # (3.0, 1.01): every source with any second-best passes, so `second` itself is what decides membership nowhere -- the distances
+    # and targets of ALL sampled sources are compared
+    assert len(want) > 0.9 * len(sample)
+
+
 def test_match_ties_quirk_and_edges(sm):
     from oracle import pyoracle
     rng = np.random.default_rng(9)

@@ -1,6 +1,6 @@
 // Times match_mfma_kernel (and an MFMA-issue-rate loop) on random packed rows.  Variants through -D:
 //   MM_VARIANT_NO_UPDATE  -- screening only, never takes the update path (upper bound of the MFMA + scan loop)
-// usage: match_variants n_src n_tgt n_split
+// usage: match_variants n_src n_tgt n_split [pre-pass length]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(int *out, int iters) {
 int main(int argc, char **argv) {
     const int ns = argc > 1 ? atoi(argv[1]) : 100000, nt = argc > 2 ? atoi(argv[2]) : 100000;
     int n_split = argc > 3 ? atoi(argv[3]) : 6;
-    const int prefix = argc > 4 ? atoi(argv[4]) : 0;
+    const int prepass = argc > 4 ? atoi(argv[4]) : 0;          // targets [0, prepass) matched by a launch of their own; its records bound every later chunk
+    int4 *bound = nullptr; hipMalloc(&bound, (size_t)2000000 * 16);
     long long split_len = (nt + n_split - 1) / n_split;
     split_len = (split_len + MM_SPLIT_QUANTUM - 1) / MM_SPLIT_QUANTUM * MM_SPLIT_QUANTUM;
     n_split = (nt + split_len - 1) / split_len;
@@ -46,29 +47,32 @@ int main(int argc, char **argv) {
     float ms;
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        if (prefix) hipMemsetAsync(part, 0x7f, (size_t)n_split * ns * 16, 0);
-        hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prefix);
+        if (prepass) hipMemsetAsync(part, 0x7f, (size_t)n_split * ns * 16, 0);
+        if (prepass) hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, 1), dim3(256), 0, 0, ds, ns, dt, dn, std::min(nt, prepass), prepass, bound, (const int4 *)nullptr);
+        hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prepass ? bound : (const int4 *)nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
 #ifdef MM_COUNT_SLOW
     { unsigned long long z = 0, v = 0; hipMemcpyToSymbol(HIP_SYMBOL(mm_slow_count), &z, 8);
-      if (prefix) hipMemset(part, 0x7f, (size_t)n_split * ns * 16);
-      hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prefix);
+      if (prepass) hipMemset(part, 0x7f, (size_t)n_split * ns * 16);
+      if (prepass) { hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, 1), dim3(256), 0, 0, ds, ns, dt, dn, std::min(nt, prepass), prepass, bound, (const int4 *)nullptr);
+                     hipDeviceSynchronize(); hipMemcpyToSymbol(HIP_SYMBOL(mm_slow_count), &z, 8); }
+      hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prepass ? bound : (const int4 *)nullptr);
       hipDeviceSynchronize(); hipMemcpyFromSymbol(&v, HIP_SYMBOL(mm_slow_count), 8);
       const double tiles = (double)groups * n_split * 4 /*waves*/ * MM_NB * (split_len / 2 / 16);
       printf("ordered updates taken: %llu of %.0f (wavefront, 16-target tile, 32-source tile) triples = %.1f %%\n", v, tiles, 100.0 * v / tiles); }
 #endif
 #ifdef MM_STAMPS
     { unsigned long long z[4] = {0, 0, 0, 0}, v[4]; hipMemcpyToSymbol(HIP_SYMBOL(mm_stamps), z, 32);
-      if (prefix) hipMemset(part, 0x7f, (size_t)n_split * ns * 16);
-      hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prefix);
+      if (prepass) hipMemset(part, 0x7f, (size_t)n_split * ns * 16);
+      hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, (const int4 *)nullptr);
       hipDeviceSynchronize(); hipMemcpyFromSymbol(v, HIP_SYMBOL(mm_stamps), 32);
       const double iters = (double)groups * n_split * 4 * (split_len / 2 / (16 * MM_TT));
       printf("stamps, cycles per wavefront-iteration (%d MFMAs = %d matrix-pipe cycles): prefetch issue %.0f, MFMA groups + screens %.0f, staging %.0f, barrier %.0f\n",
              16 * MM_TT * MM_NB / 4 * 4, 32 * 4 * MM_TT * MM_NB, v[0] / iters, v[1] / iters, v[2] / iters, v[3] / iters); }
 #endif
     const double pairs = (double)ns * nt;
-    printf("match_mfma %d x %d, %d groups x %d splits (len %lld), prefix %d: %.3f ms, %.2f Tpairs/s, %.3f PFLOP/s(i8)\n", ns, nt, groups, n_split, split_len, prefix, ms,
+    printf("match_mfma %d x %d, %d groups x %d splits (len %lld), pre-pass %d: %.3f ms, %.2f Tpairs/s, %.3f PFLOP/s(i8)\n", ns, nt, groups, n_split, split_len, prepass, ms,
            pairs / ms / 1e9, pairs * 256 / ms / 1e12);
     for (int wpb = 1; wpb <= 2; wpb++) {
         const int iters = 20000, blocks = 256 * wpb;
