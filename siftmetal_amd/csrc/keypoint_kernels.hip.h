@@ -160,8 +160,10 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
         for (int l = 0; l < ND; l++) {
             const float dv = buf[l + 1] - buf[l];
             row[l][1] = dv;
-            row[l][0] = __shfl_up(dv, 1);
-            row[l][2] = __shfl_down(dv, 1);
+            // x-1 / x+1 by DPP wavefront shifts (full-rate vector moves; a ds_bpermute per neighbour made the LDS crossbar the
+            // bound of the whole scan).  Lanes 0 and 63 keep their own value, as __shfl_up / __shfl_down would: they are halo lanes.
+            row[l][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, dv), __builtin_bit_cast(int, dv), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+            row[l][2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, dv), __builtin_bit_cast(int, dv), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
         }
     };
     const float pre = prm.dog_threshold * 0.8f;
@@ -230,7 +232,11 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
         }
         centre = __ballot(a);
     }
+#if defined(SIFTMI_EXT_ABL) && SIFTMI_EXT_ABL == 1          // tools: the launch, the flag fetch and the epilogue alone
+    const unsigned long long need = 0ull & centre;
+#else
     const unsigned long long need = centre | (centre << 1) | (centre >> 1);
+#endif
     if (need != 0ull) {
         unsigned long long todo = need;                     // needed rows not yet requested
         int last = ya - 1;
@@ -239,7 +245,11 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
             return last;
         };
         const int total = __popcll(need);
+#if defined(SIFTMI_EXT_ABL) && SIFTMI_EXT_ABL == 2          // tools: rows are read and differenced, none is tested
+        auto tested = [&](int y) { return y < -1000000; };
+#else
         auto tested = [&](int y) { return y >= ya && ((centre >> (y - (ya - 1))) & 1ull) != 0; };
+#endif
         int r0 = next_row(); issue(r0, buf0);
         int r1 = next_row(); issue(r1, buf1);
         int r2 = next_row(); issue(r2, buf2);

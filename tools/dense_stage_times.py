@@ -1,5 +1,6 @@
-"""Stage times of one 64 x 1080p step on dense natural texture (bench.py's config.dense), per-launch hipEvents.
-usage: [SIFTMI_LIB=<experiment build>] python tools/dense_stage_times.py [steps]"""
+"""Stage times of one 64 x 1080p step on dense natural texture (bench.py's config.dense) or on the benchmark frames, per-launch
+hipEvents (serialised launches: no overlap between octave chains).
+usage: [SIFTMI_LIB=<experiment build>] python tools/dense_stage_times.py [steps] [dense|bench]"""
 import os
 import sys
 
@@ -12,7 +13,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 F = 64
 eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=F)
 fs = smstream.FrameStream(eng, F)
-d = smstream.DeviceFrames(bench.make_dense_frames(F))
+kind = sys.argv[2] if len(sys.argv) > 2 else "dense"
+d = smstream.DeviceFrames(bench.make_dense_frames(F) if kind == "dense" else bench.make_frames(F, 16))
 for _ in range(2):
     fs.run(d)
 fs.synchronize()
