@@ -162,6 +162,7 @@ struct siftmi_ctx {
     hipStream_t d2h_stream = nullptr;
     std::vector<int32_t> h_counts, h_stats;
     std::vector<siftmi_match> h_matches;
+    PinnedBuf<siftmi_match> h_match_all;               // one record per source as the kernels leave them (page-locked landing buffer)
     DescriptorRec *d_match_src = nullptr, *d_match_tgt = nullptr; long long match_src_cap = 0, match_tgt_cap = 0;
     MatchRec *d_match_out = nullptr; long long match_out_cap = 0;
     int *d_match_scratch = nullptr; long long match_scratch_cap = 0;
@@ -289,7 +290,7 @@ static void free_ctx(siftmi_ctx *c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->oct_stream[i]) (void)hipStreamDestroy(c->oct_stream[i]);
     }
-    c->h_kp.release(); c->h_desc.release(); c->h_sub.release();
+    c->h_kp.release(); c->h_desc.release(); c->h_sub.release(); c->h_match_all.release();
     for (hipEvent_t e : c->ev_sub) if (e) (void)hipEventDestroy(e);
     if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
     for (int i = 0; i < 2; i++) {
@@ -1443,6 +1444,20 @@ extern "C" int siftmi_describe(siftmi_ctx *c, const siftmi_keypoint *keypoints, 
     return SIFTMI_OK;
 }
 
+// One record per source comes back through a page-locked landing buffer; the matches (target >= 0) are kept, in source order.
+static int collect_matches(siftmi_ctx *c, hipStream_t st, int64_t n_source) {
+    HIP_TRY(c->h_match_all.resize((size_t)n_source));
+    const siftmi_match *all = c->h_match_all.data();
+    HIP_TRY(hipMemcpyAsync(c->h_match_all.data(), c->d_match_out, (size_t)n_source * sizeof(MatchRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->h_matches.resize((size_t)n_source);
+    siftmi_match *out = c->h_matches.data();
+    size_t k = 0;
+    for (int64_t i = 0; i < n_source; i++) { out[k] = all[i]; k += all[i].target >= 0; }      // branch-free: every record is stored, matches advance
+    c->h_matches.resize(k);
+    return SIFTMI_OK;
+}
+
 // Launch geometry of the brute-force matcher for a problem size (also answered by siftmi_match_plan).
 struct MatchPlan { long long groups, split_len, n_split; bool bounded; };
 static MatchPlan match_plan(long long n_source, long long n_target) {
@@ -1528,8 +1543,11 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
     int4 *bound = part + n_split * n_source;                            // the pre-pass's records
     int *src_norm = (int *)(bound + n_source);
     int *tgt_norm = src_norm + n_source;
-    hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_source * 32 + 255) / 256)), dim3(256), 0, st, d_src, (int)n_source, src_packed, src_norm);
-    hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((n_target * 32 + 255) / 256)), dim3(256), 0, st, d_tgt, (int)n_target, tgt_packed, tgt_norm);
+    {
+        const unsigned sb = (unsigned)((n_source * 32 + 255) / 256), tb = (unsigned)((n_target * 32 + 255) / 256);
+        hipLaunchKernelGGL(match_prep_kernel, dim3(sb + tb), dim3(256), 0, st, d_src, (int)n_source, src_packed, src_norm, (int)sb, d_tgt, (int)n_target,
+                           tgt_packed, tgt_norm);
+    }
     // starting bound of the chunks (match_kernels.hip.h, round 4): a pre-pass over the first 512 targets, then the chunks.  Short
     // chunks go without: the bound's set-up (a clear of `part`, a dependent launch) costs what it saves there.
     const long long pre_len = 512;
@@ -1545,11 +1563,7 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
     hipLaunchKernelGGL(match_finalize_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, part, (int)n_split, src_norm, (int)n_source,
                        absolute_threshold, relative_threshold, c->d_match_out);
     HIP_TRY(hipGetLastError());
-    std::vector<siftmi_match> all((size_t)n_source);
-    HIP_TRY(hipMemcpyAsync(all.data(), c->d_match_out, (size_t)n_source * sizeof(MatchRec), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (const siftmi_match &m : all)
-        if (m.target >= 0) c->h_matches.push_back(m);                        // source order (:304-314)
+    if (int rcc = collect_matches(c, st, n_source)) return rcc;                        // source order (:304-314)
     *count = (int64_t)c->h_matches.size();
     if (matches) *matches = c->h_matches.data();
     return SIFTMI_OK;
@@ -1604,11 +1618,7 @@ extern "C" int siftmi_approximate_match(siftmi_ctx *c, const siftmi_descriptor *
     hipLaunchKernelGGL(trie_query_kernel, dim3((unsigned)((n_source + 63) / 64)), dim3(64), 0, st, d_src, (int)n_source, d_tgt, codes, idx, (int)n_target,
                        absolute_threshold, relative_threshold, c->d_match_out);
     HIP_TRY(hipGetLastError());
-    std::vector<siftmi_match> all((size_t)n_source);
-    HIP_TRY(hipMemcpyAsync(all.data(), c->d_match_out, (size_t)n_source * sizeof(MatchRec), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (const siftmi_match &m : all)
-        if (m.target >= 0) c->h_matches.push_back(m);                        // source order (:375-386)
+    if (int rcc = collect_matches(c, st, n_source)) return rcc;                        // source order (:375-386)
     *count = (int64_t)c->h_matches.size();
     if (matches) *matches = c->h_matches.data();
     return SIFTMI_OK;
