@@ -73,7 +73,7 @@ def match_extra(eng, local_rank):
     import siftmetal_amd as sm
     out = {}
     rng = np.random.default_rng(0)
-    for ns, nt in ((20000, 20000), (100000, 100000)):
+    for ns, nt in ((20000, 20000), (100000, 100000), (200000, 200000)):
         tgt = np.zeros(nt, sm.descriptor_dtype)
         tgt["features"] = np.clip(np.abs(rng.normal(0, 40, (nt, 128))), 0, 255)
         src = np.zeros(ns, sm.descriptor_dtype)

@@ -179,7 +179,10 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
         for (int nb = 0; nb < MM_NB; nb++) {
             const int s = min(s0 + nb * 32 + c, n_src - 1);
             int pub = bound[s].x;
-            for (int y = 0; y < (int)blockIdx.y; y++)
+            // (at most 8 of the predecessors, evenly spaced: with hundreds of splits a walk over all of them is a chain of L2 latencies
+            // longer than the chunk)
+            const int ystep = max(1, ((int)blockIdx.y + 7) >> 3);
+            for (int y = (int)blockIdx.y - 1; y >= 0; y -= ystep)
                 pub = min(pub, __hip_atomic_load(reinterpret_cast<const int *>(part + (long long)y * n_src + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (pub < best[nb] && pub > -MM_PAD_LIMIT) { best[nb] = pub; thr[nb] = (-best[nb]) >> 1; }
         }

@@ -1463,27 +1463,36 @@ struct MatchPlan { long long groups, split_len, n_split; bool bounded; };
 static MatchPlan match_plan(long long n_source, long long n_target) {
     MatchPlan p;
     p.groups = (n_source + MM_SRC_PER_BLOCK - 1) / MM_SRC_PER_BLOCK;
-    // Target splits: each a contiguous target range (a multiple of the staging quantum).  A CU holds 2 blocks, so 512 run at a time;
-    // blocks take equal time, so pick the split count (around 2048 blocks) whose last round is fullest.
+    // Target splits: each a contiguous target range (a multiple of the staging quantum).  A CU holds 2 blocks, so 512 run at a time.
+    // Measured (tools/match_plan_sweep.sh, round 4: 20k ... 200k squared, 2 ... 63 splits, with and without the bound):
+    //  * small problems (one round of blocks covers them with chunks of a few thousand targets): as many splits as fit ONE round,
+    //    no bound -- its pre-pass is a dependent launch of ~30 us (20k: 12 splits 0.135 ms; 30k: 8 splits 0.256 ms);
+    //  * otherwise chunks that start from a bound, 1300-2300 blocks, the count whose last round is fullest (50k: 15 splits 0.49 ms
+    //    against 0.71 for the 26 unbounded splits round 3's rule chose; 70k: 0.83 against 1.18; 100k: 10 splits 1.55; 200k: 5).
     const long long groups = p.groups;
-    long long split_len = 0;
-    {
-        const long long quanta = (n_target + MM_SPLIT_QUANTUM - 1) / MM_SPLIT_QUANTUM;
-        long long lo = (1024 + groups - 1) / groups, hi = (3072 + groups - 1) / groups;
+    const long long quanta = (n_target + MM_SPLIT_QUANTUM - 1) / MM_SPLIT_QUANTUM;
+    const long long min_q = 2048 / MM_SPLIT_QUANTUM;                                    // a bounded chunk is at least 2048 targets
+    long long q_best;
+    bool bounded;
+    if (groups * ((n_target + 2047) / 2048) <= 1024) {
+        const long long k = std::max<long long>(2, 512 / groups);
+        q_best = std::max<long long>(2, (quanta + k - 1) / k);
+        bounded = false;
+    } else {
+        const long long lo = std::max<long long>(2, (1280 + groups - 1) / groups), hi = std::max<long long>(lo, 2304 / groups);
         double best_eff = -1.0;
+        q_best = 0;
         for (long long k = lo; k <= hi; k++) {
-            long long q = (quanta + k - 1) / k;                       // quanta per split
-            if (q < 2) q = 2;
+            const long long q = std::max<long long>(min_q, (quanta + k - 1) / k);
             const long long ns = (quanta + q - 1) / q, blocks = ns * groups;
             const double eff = (double)blocks / (double)((blocks + 511) / 512 * 512);
-            if (eff > best_eff + 1e-9) { best_eff = eff; split_len = q * MM_SPLIT_QUANTUM; }
+            if (eff > best_eff + 1e-9) { best_eff = eff; q_best = q; }
         }
+        bounded = true;
     }
-    p.split_len = split_len;
-    p.n_split = (n_target + split_len - 1) / split_len;
-    // chunks start from a bound (match_kernels.hip.h, round 4) when they are long enough for its set-up (a clear of the partial
-    // records, a dependent pre-pass launch) to pay
-    p.bounded = p.n_split >= 2 && split_len >= 4096;
+    p.split_len = q_best * MM_SPLIT_QUANTUM;
+    p.n_split = (n_target + p.split_len - 1) / p.split_len;
+    p.bounded = bounded && p.n_split >= 2;
     return p;
 }
 

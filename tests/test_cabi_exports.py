@@ -72,13 +72,17 @@ def test_match_plan_covers_every_target_once(lib):
     when they are long (the size class tests/test_gpu_parity.py::test_match_large_bounded_chunks_* exercises)."""
     sl, ns, b = C.c_int64(), C.c_int64(), C.c_int()
     seen_bounded = set()
-    for n_src, n_tgt in [(1, 1), (5, 3), (300, 1000), (5000, 12000), (20000, 20000), (32845, 200013), (100000, 100000), (700, 3000000)]:
+    for n_src, n_tgt in [(1, 1), (5, 3), (300, 1000), (5000, 12000), (20000, 20000), (50000, 50000), (32845, 200013), (100000, 100000), (700, 3000000),
+                         (100000, 3000)]:
         assert lib.siftmi_match_plan(n_src, n_tgt, C.byref(sl), C.byref(ns), C.byref(b)) == 0
         assert sl.value > 0 and sl.value % 64 == 0
         assert ns.value * sl.value >= n_tgt > (ns.value - 1) * sl.value
-        assert bool(b.value) == (ns.value >= 2 and sl.value >= 4096)
         groups = (n_src + 511) // 512
-        assert ns.value * groups <= max(3072 + groups, (n_tgt + 127) // 128 * groups)
+        if b.value:
+            assert ns.value >= 2 and sl.value >= 2048              # the pre-pass (512 targets) lies inside the first chunk
+            assert ns.value * groups <= 2304 + groups
+        else:
+            assert ns.value * groups <= max(512, groups * 2)       # one round of workgroups
         seen_bounded.add(bool(b.value))
     assert seen_bounded == {False, True}
     assert lib.siftmi_match_plan(0, 5, None, None, None) != 0

@@ -532,15 +532,15 @@ def test_match_random_vs_oracle(sm, n_src, n_tgt):
     assert max(n_found) > 0 or n_src <= 5
 
 
-def test_match_large_bounded_chunks_sampled_sources_vs_oracle(sm):
+@pytest.mark.parametrize("n_src,n_tgt", [(32768 + 77, 200000 + 13), (45000 + 3, 50000 + 7)])
+def test_match_large_bounded_chunks_sampled_sources_vs_oracle(sm, n_src, n_tgt):
     """The size class where chunks start from a bound (pre-pass over the first 512 targets + the published bests of earlier chunks,
     match_kernels.hip.h round 4).  Sources are independent, so the oracle checks a sample of them over ALL targets, bit-exact in
     the indices; duplicated targets in different chunks pin the first-occurrence and `second` rules across chunk borders."""
     from oracle import pyoracle
-    n_src, n_tgt = 32768 + 77, 200000 + 13
     eng = sm.Engine(64, 64, n_octaves=1)
     split_len, n_split, bounded = eng.match_plan(n_src, n_tgt)
-    assert bounded and n_split >= 2 and split_len >= 4096, (split_len, n_split, bounded)
+    assert bounded and n_split >= 2 and split_len >= 2048, (split_len, n_split, bounded)
     rng = np.random.default_rng(4242)
     tgt = _sift_like(rng, n_tgt)
     # exact duplicates of early targets late in the list (other chunks), and of late targets early
