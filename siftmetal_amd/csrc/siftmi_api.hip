@@ -786,8 +786,13 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     }
     hipStream_t cur = st;
     bool joined[MAX_OCT] = {};
+    int fork_width = 0;                                       // chains a forked sequence may use (0: one per octave)
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_FORK_WIDTH")) fork_width = atoi(e);
+#endif
     for (int o = 0; o < c->n_oct; o++) {
         hipStream_t next = cur;
+        const bool fork_here = fork && o + 1 < c->n_oct && (fork_width == 0 || o + 1 < fork_width);
         // DoG activity flags for the extrema scan: only when every layer of this octave goes through the marching blur
         const int chain = chain_tile(c, o, nf);
         // (dense_hint, set by the frame stream from earlier steps' descriptor totals: on frames that are texture throughout every row
@@ -802,7 +807,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
             t_begin(c, SIFTMI_T_BLUR, o * 16 + 1);
             HIP_TRY(launch_blur_chain(c, cur, gauss_ptr(c, o, 0), c->ow[o], c->oh[o], nf, 0, dec.dst ? c->nspo : 0, dec));
             t_end(c);
-            if (fork && o + 1 < c->n_oct) {
+            if (fork_here) {
                 HIP_TRY(hipEventRecord(c->ev_fork[o], cur));
                 next = c->oct_stream[o + 1];
                 HIP_TRY(hipStreamWaitEvent(next, c->ev_fork[o], 0));
@@ -825,7 +830,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
             HIP_TRY((launch_blur<false>(c, cur, (c->taps[s - 1] - 1) / 2, gauss_ptr(c, o, s - 1), gauss_ptr(c, o, s), c->ow[o], c->oh[o],
                                         nf, c->layer_w[s - 1], none, dec, act)));
             t_end(c);
-            if (fork && s == c->nspo && o + 1 < c->n_oct) {          // next octave can start now, on its own stream
+            if (fork_here && s == c->nspo) {                          // next octave can start now, on its own stream
                 HIP_TRY(hipEventRecord(c->ev_fork[o], cur));
                 next = c->oct_stream[o + 1];
                 HIP_TRY(hipStreamWaitEvent(next, c->ev_fork[o], 0));
@@ -1268,7 +1273,11 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
         // of the next sub-batch waits for this one's kernels instead of running under them (measured: 19.5-19.8 ms per 64 x 1080p
         // call forked, 14.8-16.0 one chain; with the copy streams on hardware queues of their own -- SIFTMI_COPY_STREAM_PRIORITY=1
         // -- 16.4-16.7 forked).
-        auto enqueue_g = [&](bool fork) { return enqueue(fork && on_device != 0); };
+        bool host_fork = false;
+#ifdef SIFTMI_EXPERIMENT
+        host_fork = getenv("SIFTMI_EXP_HOST_FORK") != nullptr;
+#endif
+        auto enqueue_g = [&](bool fork) { return enqueue(fork && (on_device != 0 || host_fork)); };
         if ((rc = replay_or_capture(c, st, key, enqueue_g, &launched))) return rc;
         if (!launched && (rc = enqueue(false))) return rc;
         if ((rc = input_consumed(c, on_device))) return rc;
