@@ -12,8 +12,9 @@
 //     if (b < best) { second = min(best, s); best = b; idx = i; }
 // which is how the kernel below parallelises the scan without changing its result.
 // Distances: the reference takes the f32 Euclidean distance of features/255; here the squared distance of
-// the 0..255 integers is formed exactly in int32 (bytes re-biased by 128 to signed i8, v_dot4_i32_i8:
-// |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b', shift-invariant) and distance = sqrt(D) / 255 in f32; the two agree
+// the 0..255 integers is formed exactly in int32 (bytes re-biased to signed i8, int8 MFMA / v_dot4_i32_i8:
+// |a-b|^2 = [source norm] + [target norm] + 2 a'.v with a' = 127 - a, v = b - 128, see match_prep_kernel) and distance =
+// sqrt(D) / 255 in f32; the two agree
 // to f32 rounding (~1e-6 relative), which only matters on threshold knife edges.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -89,6 +90,7 @@ constexpr int MM_SPLIT_QUANTUM = 32 * MM_TT;               // a split's target r
 constexpr int MM_ROW = 144;                                // LDS row stride in bytes: 128 + 16 -> conflict-free ds_read_b128
 constexpr int MM_NONE = 0x7fffffff;
 constexpr int MM_PAD_NORM = 0x03ffffff;                    // |b|^2 of a padding row: its key can never win (and (acc << 5) still fits)
+__device__ __forceinline__ int mm_thr(int best) { return (best >> 1) + (best & 1); }     // ceil(best / 2): acc < thr is necessary for key < best
 constexpr int MM_PAD_LIMIT = 0x02000000;                   // real keys are below 2^23
 
 // features -> dense rows of 128 re-biased int8 (32 dwords) + |b'|^2.  32 threads per descriptor.
@@ -103,12 +105,17 @@ __global__ __launch_bounds__(256) void match_prep_kernel(const DescriptorRec *__
     int *__restrict__ norm = is_src ? norm_src : norm_tgt;
     const long long gid = (long long)(is_src ? blockIdx.x : blockIdx.x - src_blocks) * 256 + threadIdx.x;
     const int i = (int)(gid >> 5), k = (int)(gid & 31);
+    // Bytes re-biased to signed: v = f - 128.  Targets are packed as v; sources as 127 - f = ~v, so that the MFMA chain yields
+    // MINUS the products the distance needs (round 4: key = 2 acc + parity is then one v_lshl_add in the ordered scan).  With
+    // a' = 127 - f_a and v = f_b - 128:  |f_a - f_b|^2 = sum (f_a - 128)^2 + [sum (f_b - 127)^2 - 128] + 2 a'.v -- the first term is
+    // the source's norm, the bracket the target's.
     int v = 0;
     if (i < n) {
         v = reinterpret_cast<const int *>(d[i].features)[k] ^ (int)0x80808080;
-        packed[(long long)i * 32 + k] = v;
+        packed[(long long)i * 32 + k] = is_src ? ~v : v;
     }
     int nb = dot4(v, v, 0);
+    if (!is_src) nb = dot4(v, 0x02020202, nb);                 // |v|^2 + 2 sum v = sum (v + 1)^2 - 128
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) nb += __shfl_xor(nb, o, 64);
     if (i < n && k == 0) norm[i] = nb;
@@ -122,8 +129,8 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
                        int4 *__restrict__ part /* [gridDim.y][n_src]: best, idx, second */,
                        const int4 *__restrict__ bound /* or null: [n_src] records of a pre-pass over targets [0, P), P <= split_len */) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][MM_TT][32 * MM_ROW];
-    __shared__ __attribute__((aligned(16))) int lds_c[2][MM_TT][32];    // C-in of the MFMA chain: -(|b'|^2 >> 1)
-    __shared__ __attribute__((aligned(16))) int lds_n[2][MM_TT][32];    // |b'|^2 (only read on the ordered-update path)
+    __shared__ __attribute__((aligned(16))) int lds_c[2][MM_TT][32];    // C-in of the MFMA chain: the target's norm >> 1
+    __shared__ __attribute__((aligned(16))) int lds_n[2][MM_TT][32];    // parity bit of the target's norm (only read on the ordered-update path)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 31, h = lane >> 5;
     const int half_len = split_len >> 1, n_iter = half_len / (16 * MM_TT);
     const int t_lo = blockIdx.y * split_len, t_hi = min(n_tgt, t_lo + split_len);
@@ -155,17 +162,17 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
         for (int j = 0; j < MM_TT; j++) {
             *reinterpret_cast<i32x4 *>(&lds_a[buf][j][r * MM_ROW + p * 16]) = pre_v[j];
             if (p == 0) {
-                lds_c[buf][j][hr * 16 + pos] = -(pre_n[j] >> 1);
-                lds_n[buf][j][hr * 16 + pos] = pre_n[j];
+                lds_c[buf][j][hr * 16 + pos] = pre_n[j] >> 1;     // (arithmetic: a target's norm can be as low as -128)
+                lds_n[buf][j][hr * 16 + pos] = pre_n[j] & 1;
             }
         }
     };
-    // key = |b'|^2 - 2 a'.b' (the distance without the per-source constant |a'|^2).  The chain starts from
-    // C = -(|b'|^2 >> 1), so acc = a'.b' - (|b'|^2 >> 1) and key = (|b'|^2 & 1) - 2 acc.  Screening test on acc alone:
-    // key < best  =>  acc > floor(-best / 2) = thr  (exact up to the parity bit; the ordered path re-tests exactly).
+    // key = N_b + 2 a'.v (the distance without the per-source constant; N_b = the target's norm, see match_prep_kernel).  The chain
+    // starts from C = N_b >> 1, so acc = a'.v + (N_b >> 1) and key = 2 acc + (N_b & 1).  Screening test on acc alone:
+    // key < best  =>  acc < ceil(best / 2) = thr  (exact up to the parity bit; the ordered path re-tests exactly).
     int best[MM_NB], idx[MM_NB], second[MM_NB], thr[MM_NB];
 #pragma unroll
-    for (int nb = 0; nb < MM_NB; nb++) { best[nb] = MM_NONE; idx[nb] = -1; second[nb] = MM_NONE; thr[nb] = (-MM_NONE) >> 1; }
+    for (int nb = 0; nb < MM_NB; nb++) { best[nb] = MM_NONE; idx[nb] = -1; second[nb] = MM_NONE; thr[nb] = mm_thr(MM_NONE); }
 
     // ---- the starting bound of a chunk that does not begin at target 0 (round 4): the best key of the pre-pass -- this same kernel
     // launched over targets [0, P) alone, P <= split_len, its records in `bound` --
@@ -184,7 +191,7 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
             const int ystep = max(1, ((int)blockIdx.y + 7) >> 3);
             for (int y = (int)blockIdx.y - 1; y >= 0; y -= ystep)
                 pub = min(pub, __hip_atomic_load(reinterpret_cast<const int *>(part + (long long)y * n_src + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (pub < best[nb] && pub > -MM_PAD_LIMIT) { best[nb] = pub; thr[nb] = (-best[nb]) >> 1; }
+            if (pub < best[nb] && pub > -MM_PAD_LIMIT) { best[nb] = pub; thr[nb] = mm_thr(best[nb]); }
         }
     }
 
@@ -246,13 +253,13 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int nb = nb0 + u;
-                int tmax = acc[u][0];
+                int tmin = acc[u][0];
 #pragma unroll
-                for (int i = 1; i < 16; i++) tmax = max(tmax, acc[u][i]);
+                for (int i = 1; i < 16; i++) tmin = min(tmin, acc[u][i]);
 #ifdef MM_VARIANT_NO_UPDATE
-                if (tmax > 0x7ffffff0) { best[nb] = tmax; idx[nb] = tbase; }
+                if (tmin < -0x7ffffff0) { best[nb] = tmin; idx[nb] = tbase; }
 #else
-                if (tmax > thr[nb]) {                    // some lane may improve: ordered update, exactly the reference's scan
+                if (tmin < thr[nb]) {                    // some lane may improve: ordered update, exactly the reference's scan
 #ifdef MM_COUNT_SLOW
                     if (lane == __builtin_ctzll(__ballot(true))) atomicAdd(&mm_slow_count, 1ull);
 #endif
@@ -262,11 +269,11 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
                         const i32x4 pv = *reinterpret_cast<const i32x4 *>(&lds_n[cur][j][h * 16 + g * 4]);
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            const int key = (pv[e] & 1) - 2 * acc[u][g * 4 + e];
+                            const int key = (acc[u][g * 4 + e] << 1) + pv[e];           // pv: the parity bit of the target's norm
                             if (key < best[nb]) { second[nb] = best[nb]; best[nb] = key; at = g * 4 + e; }
                         }
                     }
-                    if (at >= 0) { idx[nb] = tbase + at; thr[nb] = (-best[nb]) >> 1; }
+                    if (at >= 0) { idx[nb] = tbase + at; thr[nb] = mm_thr(best[nb]); }
                 }
 #endif
             }
