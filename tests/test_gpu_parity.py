@@ -463,7 +463,7 @@ def test_dense_natural_texture_1080p_vs_oracle(sm, butterfly_bgra):
         in_ori = parity.to_oracle_orientations(g_ori)
         r_desc, r_f32 = orc.descriptors(o, okp, in_ori, want_float=True)
         drep = parity.compare_descriptors(got_d[o], eng.descriptor_floats(o), r_desc, r_f32, in_ori)
-        assert drep["max_bin_diff"] <= 1 and drep["frac_differing"] <= parity.MAX_DESC_BIN_FRAC and drep["max_l2_float"] <= parity.TOL_DESC_L2, drep
+        assert drep["max_bin_diff"] <= 1 and drep["bins_differing"] <= parity.bins_allowed(drep["bins"]) and drep["max_l2_float"] <= parity.TOL_DESC_L2, drep
     assert match >= 0.995 * tot, (match, tot)
 
 
