@@ -239,6 +239,11 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 #pragma unroll
                 for (int m = 1; m < 4; m++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[nb0 + u][m], acc[u], 0, 0, 0);
             }
+#ifdef MM_SCHED_BARRIER
+            // keep the compiler from sinking this group's MFMAs below the previous group's screen (it interleaved the two groups' chains,
+            // put a chain's last MFMA right in front of its screen and padded the result hazard with s_nop 6-10)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         auto screen = [&](i32x16 (&acc)[2], int nb0, int j) {
             const int tbase = t_lo + h * half_len + (it * MM_TT + j) * 16;
@@ -253,6 +258,10 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int nb = nb0 + u;
+#ifdef MM_VARIANT_NO_SCREEN                              // tools/ubench: the MFMA feed alone (one vector instruction keeps the chain alive)
+                best[nb] ^= acc[u][0] & acc[u][15]; idx[nb] = 0;
+                continue;
+#endif
                 int tmin = acc[u][0];
 #pragma unroll
                 for (int i = 1; i < 16; i++) tmin = min(tmin, acc[u][i]);
