@@ -80,6 +80,9 @@ __device__ unsigned long long mm_stamps[4];                // tools/ubench: wave
 #ifndef MM_CIN_DEF                                         // 1: -(|b'|^2 >> 1) enters as the MFMA chain's C operand (16 registers per set);
 #define MM_CIN_DEF 1                                       // 0: chains start from 0 and the screen adds it (16 more vector adds per 4 MFMAs)
 #endif
+#ifndef MM_XPF_DEF                                         // 1: three LDS buffers; the A fragments / C-in of the NEXT iteration's first tile are read
+#define MM_XPF_DEF 0                                       // before the barrier (needs MM_PIPE_DEF).  Measured: no gain (1.52-1.54 against 1.41-1.50 ms), off
+#endif
 #ifndef MM_WAVES_DEF
 #define MM_WAVES_DEF 2
 #endif
@@ -128,9 +131,11 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
                        const int *__restrict__ tgt_norm, int n_tgt, int split_len /* multiple of MM_SPLIT_QUANTUM */,
                        int4 *__restrict__ part /* [gridDim.y][n_src]: best, idx, second */,
                        const int4 *__restrict__ bound /* or null: [n_src] records of a pre-pass over targets [0, P), P <= split_len */) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][MM_TT][32 * MM_ROW];
-    __shared__ __attribute__((aligned(16))) int lds_c[2][MM_TT][32];    // C-in of the MFMA chain: the target's norm >> 1
-    __shared__ __attribute__((aligned(16))) int lds_n[2][MM_TT][32];    // parity bit of the target's norm (only read on the ordered-update path)
+    constexpr bool XPF = MM_XPF_DEF && MM_PIPE_DEF && MM_TT == 2;
+    constexpr int NBUF = XPF ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[NBUF][MM_TT][32 * MM_ROW];
+    __shared__ __attribute__((aligned(16))) int lds_c[NBUF][MM_TT][32];    // C-in of the MFMA chain: the target's norm >> 1
+    __shared__ __attribute__((aligned(16))) int lds_n[NBUF][MM_TT][32];    // parity bit of the target's norm (only read on the ordered-update path)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 31, h = lane >> 5;
     const int half_len = split_len >> 1, n_iter = half_len / (16 * MM_TT);
     const int t_lo = blockIdx.y * split_len, t_hi = min(n_tgt, t_lo + split_len);
@@ -196,6 +201,7 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
     }
 
     if (n_iter > 0) { prefetch(0); stage(0); }
+    if (XPF && n_iter > 1) { prefetch(1); stage(1); }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the source fragments have landed, so the loop's only VMEM waits are its prefetches
     __syncthreads();
     // Software pipeline inside an iteration (round 4).  The work of an iteration is G = MM_TT x MM_NB / 2 groups of 8 MFMAs (one
@@ -211,26 +217,34 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
     unsigned long long mm_t_, mm_acc_[4] = {0, 0, 0, 0};
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mm_t_)::"memory");
 #endif
-    for (int it = 0; it < n_iter; it++) {
-        const int cur = it & 1;
+    // XPF (round 4 experiment, off): with two LDS buffers every wavefront begins an iteration -- right behind the barrier -- with 16
+    // ds_read_b128 for its first tile, all eight wavefronts of a CU at once.  With THREE buffers the targets of iteration it + 2 are
+    // staged at the end of iteration it, so iteration it + 1's buffer is complete a whole iteration early and its first tile's
+    // fragments are read during iteration it's last groups, into the fragment set the first tile has finished with.  Same results,
+    // no gain: that burst is not where the matrix pipe's idle time comes from (profiles/match_variants_r04_occupancy.log).
+    constexpr int NSET = MM_PIPE_DEF ? 2 : 1;
+    i32x4 af[NSET][4];
+    i32x16 cinf[NSET];
+    auto load_frags = [&](int buf, int j, i32x4 (&a)[4], i32x16 &cin) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const i32x4 *>(&lds_a[buf][j][c * MM_ROW + m * 32 + h * 16]);
+        if (MM_CIN_DEF) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[buf][j][h * 16 + q * 4]);
+                cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
+            }
+        }
+    };
+    if (XPF && n_iter > 0) load_frags(0, 0, af[0], cinf[0]);
+    int cur = 0;
+    for (int it = 0; it < n_iter; it++, cur = (cur + 1 == NBUF ? 0 : cur + 1)) {
+        const int nxt = cur + 1 == NBUF ? 0 : cur + 1;             // the buffer of iteration it + 1
+        const int fill = XPF ? (nxt + 1 == NBUF ? 0 : nxt + 1) : nxt;   // the buffer this iteration stages (it + 2 with XPF, it + 1 without)
 #ifndef MM_VARIANT_NO_LOAD
-        if (it + 1 < n_iter) prefetch(it + 1);
+        if (it + (XPF ? 2 : 1) < n_iter) prefetch(it + (XPF ? 2 : 1));
 #endif
         MM_STAMP(0);
-        constexpr int NSET = MM_PIPE_DEF ? 2 : 1;
-        i32x4 af[NSET][4];
-        i32x16 cinf[NSET];
-        auto load_frags = [&](int j, i32x4 (&a)[4], i32x16 &cin) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) a[m] = *reinterpret_cast<const i32x4 *>(&lds_a[cur][j][c * MM_ROW + m * 32 + h * 16]);
-            if (MM_CIN_DEF) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const i32x4 v = *reinterpret_cast<const i32x4 *>(&lds_c[cur][j][h * 16 + q * 4]);
-                    cin[q * 4 + 0] = v[0]; cin[q * 4 + 1] = v[1]; cin[q * 4 + 2] = v[2]; cin[q * 4 + 3] = v[3];
-                }
-            }
-        };
         auto issue = [&](const i32x4 (&a)[4], const i32x16 &cin, int nb0, i32x16 (&acc)[2]) {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -289,12 +303,14 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
         };
         i32x16 acc[NSET][2];
         if (MM_PIPE_DEF) {
-            load_frags(0, af[0], cinf[0]);
+            if (!XPF) load_frags(cur, 0, af[0], cinf[0]);
             issue(af[0], cinf[0], 0, acc[0]);
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const int j = g / PAIRS, pr = g % PAIRS;
-                if (pr == 0 && j + 1 < MM_TT) load_frags(j + 1, af[(j + 1) % NSET], cinf[(j + 1) % NSET]);   // a tile ahead of its first MFMA
+                if (pr == 0 && j + 1 < MM_TT) load_frags(cur, j + 1, af[(j + 1) % NSET], cinf[(j + 1) % NSET]);   // a tile ahead of its first MFMA
+                // XPF: tile 0's last group was issued at step PAIRS - 2 (or before the loop): its fragment set is free from step PAIRS on
+                if (XPF && g == PAIRS && it + 1 < n_iter) load_frags(nxt, 0, af[0], cinf[0]);
                 if (g + 1 < G) {
                     const int jn = (g + 1) / PAIRS, prn = (g + 1) % PAIRS;
                     issue(af[jn % NSET], cinf[jn % NSET], 2 * prn, acc[(g + 1) % NSET]);
@@ -305,14 +321,14 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const int j = g / PAIRS, pr = g % PAIRS;
-                if (pr == 0) load_frags(j, af[0], cinf[0]);
+                if (pr == 0) load_frags(cur, j, af[0], cinf[0]);
                 issue(af[0], cinf[0], 2 * pr, acc[0]);
                 screen(acc[0], 2 * pr, j);
             }
         }
         MM_STAMP(1);
 #ifndef MM_VARIANT_NO_LOAD
-        if (it + 1 < n_iter) stage(cur ^ 1);
+        if (it + (XPF ? 2 : 1) < n_iter) stage(fill);
 #endif
         MM_STAMP(2);
 #ifndef MM_VARIANT_NO_BARRIER
