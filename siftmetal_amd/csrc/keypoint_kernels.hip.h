@@ -783,15 +783,17 @@ __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, 
 // COOP (as descriptor_kernel): the four wavefronts of a workgroup share one keypoint -- on a frame or two there are fewer keypoints
 // than wavefront slots and a window of ~850 samples is 13 dependent rounds for one wavefront, 4 for a workgroup.  Same samples
 // into the same u64 fixed-point bins: bit-identical.
-template <bool COOP>
-__global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectParams prm,
+// WPB: wavefronts per workgroup (COOP = false), see descriptor_kernel
+template <bool COOP, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void orientation_kernel(PyramidDesc P, DetectParams prm,
                                                          const KeypointRec *__restrict__ kps, const int32_t *__restrict__ kp_count,
                                                          int32_t *__restrict__ ori_count, float *__restrict__ ori_angles) {
     // 4 private copies of the 36-bin histogram per wave (copy = lane % 4), 37 u64 apart so that the copies of a bin sit on
     // different LDS banks: neighbouring lanes (neighbouring pixels) mostly share a bin, and same-address lanes of one
     // ds_add_u64 serialise
     constexpr int OCOPY = SIFTMI_ORI_NCOPY, OSTRIDE = ORI_BINS + 1;
-    __shared__ unsigned long long hist_all[4][OCOPY * OSTRIDE];
+    static_assert(WPB == 4 || (!COOP && WPB == 1), "COOP shares one keypoint among the four wavefronts of a workgroup");
+    __shared__ unsigned long long hist_all[WPB][OCOPY * OSTRIDE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long *hist0 = hist_all[COOP ? 0 : wv];
     unsigned long long *hist = hist0 + (lane & (OCOPY - 1)) * OSTRIDE;
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(PyramidDesc P, DetectP
     const int w = P.w[o], h = P.h[o];
     const float delta = P.delta[o], lambda = prm.lambda_ori;
     const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
-    const int k_first = COOP ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wv), k_step = COOP ? (int)gridDim.x : (int)(gridDim.x * 4);
+    const int k_first = COOP ? (int)blockIdx.x : (int)(blockIdx.x * WPB + wv), k_step = COOP ? (int)gridDim.x : (int)(gridDim.x * WPB);
     KeypointRec kp_next = kps[base + min(k_first, max(n - 1, 0))];      // the record of a wave's NEXT keypoint is requested a keypoint ahead
     for (int k = k_first; k < n; k += k_step) {
         const KeypointRec kp = kp_next;
@@ -963,8 +965,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 // COOP = true: the four wavefronts of a workgroup share one descriptor -- for a frame or two there are fewer descriptors than
 // wavefront slots, and a descriptor's ~3000 samples walked by 64 lanes take 60-100 us of dependent loads and LDS atomics;
 // four waves cut that to a quarter.  Same samples into the same u64 fixed-point bins, so the result is bit-identical.
-template <bool COOP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
+// WPB = wavefronts per workgroup (COOP = false only): 4, or 1 -- a workgroup's LDS and wave slots are held until its LAST wavefront is
+// done, and descriptors differ 4x in their sample count, so with four independent wavefronts per workgroup a quarter of the slots
+// idles at workgroup tails on dense frames (4.35 of 6 resident, PMC round 4)
+template <bool COOP, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
                                                         float *__restrict__ desc_f32 /* may be null */) {
@@ -977,9 +982,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
     // arithmetic than it saved.)  u64 fixed point: see fix32_product.
     constexpr int NCOPY = SIFTMI_DESC_NCOPY;
     constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
-    __shared__ unsigned long long patch_all[4][NCOPY * DESC_N];
-    __shared__ int col_start_all[4][MAXCOL + 1];
-    __shared__ short col_lo_all[4][MAXCOL];
+    static_assert(WPB == 4 || (!COOP && WPB == 1), "COOP shares one descriptor among the four wavefronts of a workgroup");
+    __shared__ unsigned long long patch_all[WPB][NCOPY * DESC_N];
+    __shared__ int col_start_all[WPB][MAXCOL + 1];
+    __shared__ short col_lo_all[WPB][MAXCOL];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hw_ = COOP ? 0 : wv;                          // whose histogram copies: the workgroup's (COOP) or this wave's
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
@@ -994,7 +1000,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void d
     const float delta = P.delta[o];
     const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
     const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
-    for (int di = COOP ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wv); di < n; di += COOP ? (int)gridDim.x : (int)(gridDim.x * 4)) {
+    for (int di = COOP ? (int)blockIdx.x : (int)(blockIdx.x * WPB + wv); di < n; di += COOP ? (int)gridDim.x : (int)(gridDim.x * WPB)) {
         const DescInput in = desc_in[dbase + di];
         const KeypointRec kp = kps[kbase + in.keypoint];
         const float theta = in.theta;

@@ -894,11 +894,22 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     StageRange rg("siftmi orientation + descriptors (getDescriptors)");
     t_begin(c, SIFTMI_T_ORIENT);
     const bool coop = (long long)nf * c->ow[0] * c->oh[0] <= small_launch_pixels();   // a frame or two: a whole workgroup per keypoint / descriptor
+    // Large launches: ONE wavefront per workgroup (round 4).  Four independent wavefronts per workgroup held its LDS and wave slots
+    // until the slowest was done; keypoints and descriptors differ 4x in window size.  Measured, 64 x 1080p: descriptors 1.20 -> 1.04 ms
+    // on the benchmark frames, 6.46 -> 6.2 ms on dense texture (tools/dense_stage_times.py); the records do not depend on it.
+    int wpb_ori = 1, wpb_desc = 1;
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_ORI_WPB")) wpb_ori = atoi(e);
+    if (const char *e = getenv("SIFTMI_EXP_DESC_WPB")) wpb_desc = atoi(e);
+#endif
     if (coop)
-        hipLaunchKernelGGL(orientation_kernel<true>, dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+        hipLaunchKernelGGL((orientation_kernel<true, 4>), dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+                           c->d_ori_angles);
+    else if (wpb_ori == 1)
+        hipLaunchKernelGGL((orientation_kernel<false, 1>), dim3(1024, groups), dim3(64), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                            c->d_ori_angles);
     else
-        hipLaunchKernelGGL(orientation_kernel<false>, dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+        hipLaunchKernelGGL((orientation_kernel<false, 4>), dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                            c->d_ori_angles);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(expand_descriptors_kernel, dim3(groups), dim3(1024), 0, st, P, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
@@ -908,11 +919,16 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     t_begin(c, SIFTMI_T_DESCRIBE);
     // a frame or two: fewer descriptors than wavefront slots -> one workgroup per descriptor (see descriptor_kernel)
     if (coop)
-        hipLaunchKernelGGL(descriptor_kernel<true>, dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+        hipLaunchKernelGGL((descriptor_kernel<true, 4>), dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                            c->d_desc_f32);
-    else
-        hipLaunchKernelGGL(descriptor_kernel<false>, dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
-                           c->d_desc_f32);
+    else {
+        if (wpb_desc == 1)
+            hipLaunchKernelGGL((descriptor_kernel<false, 1>), dim3(1024, groups), dim3(64), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+                               c->d_desc_f32);
+        else
+            hipLaunchKernelGGL((descriptor_kernel<false, 4>), dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+                               c->d_desc_f32);
+    }
     HIP_TRY(hipGetLastError());
     t_end(c);
     return SIFTMI_OK;
