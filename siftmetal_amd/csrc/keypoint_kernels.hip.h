@@ -96,8 +96,10 @@ constexpr int EXT_COLS_PER_WAVE = 62, EXT_COLS_PER_BLOCK = 4 * EXT_COLS_PER_WAVE
 // vertical neighbour is active.  On the benchmark frames 88 % of octave 0's row segments are inactive.  The emitted
 // candidate list is exactly the same; raw_count then only counts the extrema of tested rows (cfg.count_raw_extrema = 1
 // turns the flags off and restores the full count).
-template <int NS, bool SKIP = false>
-__global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParams prm, int o, int EH,
+// WPB: wavefronts per workgroup (4, or 1 -- the wavefronts of a workgroup scan independent column strips and only meet at the list
+// flush; on flagged frames their row counts differ widely and a workgroup's slots stay held until the busiest is done)
+template <int NS, bool SKIP = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void extrema_kernel(PyramidDesc P, DetectParams prm, int o, int EH,
                                                      ExtremumRec *__restrict__ lists, int32_t *__restrict__ cand_count,
                                                      int32_t *__restrict__ raw_count, const unsigned char *__restrict__ act /* octave planes, frame 0 */,
                                                      size_t act_frame_stride, int ncell) {
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
     // Workgroup-level staging (as the reference's threadgroup array, SIFTExtrema.metal:71-75, 101-109):
     // one global atomic per workgroup and counter.  A single device-scope counter serialises at
     // ~12 ns per atomic on MI355X, which at one atomic per extremum cost more than the whole scan.
-    constexpr int STAGE = 1024;
+    constexpr int STAGE = 256 * WPB;
     __shared__ ExtremumRec stage[STAGE];
     __shared__ int s_cand, s_raw, s_base;
     if (threadIdx.x == 0) { s_cand = 0; s_raw = 0; }
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
     const int w = P.w[o], h = P.h[o];
     const int frame = blockIdx.z, group = frame * P.n_octaves + o;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = blockIdx.x * EXT_COLS_PER_BLOCK + wv * EXT_COLS_PER_WAVE + lane;      // lane 0 = column x0-1 ... (first output column is 1)
+    const int x = blockIdx.x * (WPB * EXT_COLS_PER_WAVE) + wv * EXT_COLS_PER_WAVE + lane;      // lane 0 = column x0-1 ... (first output column is 1)
     const int ya = blockIdx.y * EH + 1;                    // first output row of this block
     const int yb = min(ya + EH, h - 1);                    // one past the last output row
     if (ya >= yb || w < 3) return;                         // uniform for the workgroup
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
     if (!SKIP) {
         centre = ((1ull << (yb - ya)) - 1ull) << 1;                                       // rows ya ... yb-1 (EH + 2 <= 64)
     } else {
-        const int xw = blockIdx.x * EXT_COLS_PER_BLOCK + wv * EXT_COLS_PER_WAVE;          // column of lane 0
+        const int xw = blockIdx.x * (WPB * EXT_COLS_PER_WAVE) + wv * EXT_COLS_PER_WAVE;   // column of lane 0
         const int c0 = min((xw + 1) >> 6, ncell - 1), c1 = min((xw + EXT_COLS_PER_WAVE) >> 6, ncell - 1);
         const unsigned char *ap = act + (size_t)frame * act_frame_stride;
         bool a = false;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(PyramidDesc P, DetectParam
     }
     __syncthreads();
     const int base = s_base;
-    for (int i = threadIdx.x; i < nloc; i += 256)
+    for (int i = threadIdx.x; i < nloc; i += 64 * WPB)
         if (base + i < P.cap_ext[o]) glist[base + i] = stage[i];
 }
 

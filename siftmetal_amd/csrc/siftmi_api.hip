@@ -720,16 +720,20 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
         while (EH > 6 && cols * ((c->oh[o] - 2 + EH - 1) / EH) * nf < 1024) EH -= 3;
     }
     t_begin(c, SIFTMI_T_EXTREMA);
-    dim3 grid((c->ow[o] - 2 + EXT_COLS_PER_BLOCK - 1) / EXT_COLS_PER_BLOCK, (c->oh[o] - 2 + EH - 1) / EH, nf);
+    int wpb = 4;
+#ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_EXT_WPB")) wpb = atoi(e);
+#endif
+    const int cols_per_wg = (wpb == 1 ? 1 : 4) * EXT_COLS_PER_WAVE;
+    dim3 grid((c->ow[o] - 2 + cols_per_wg - 1) / cols_per_wg, (c->oh[o] - 2 + EH - 1) / EH, nf);
     const unsigned char *actp = c->act_valid[o] ? c->d_act + c->act_off[o] : nullptr;
+#define LAUNCH_EXT_W(NS, SK, W)                                                                                                           \
+    hipLaunchKernelGGL((extrema_kernel<NS, SK, W>), grid, dim3(64 * W), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW), actp, \
+                       c->act_frame, c->act_ncell[o])
 #define LAUNCH_EXT(NS)                                                                                                                    \
     do {                                                                                                                                  \
-        if (actp)                                                                                                                         \
-            hipLaunchKernelGGL((extrema_kernel<NS, true>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW), actp, \
-                               c->act_frame, c->act_ncell[o]);                                                                            \
-        else                                                                                                                              \
-            hipLaunchKernelGGL((extrema_kernel<NS, false>), grid, dim3(256), 0, st, c->P, c->prm, o, EH, c->d_ext, cnt(c, C_CAND), cnt(c, C_RAW), actp, \
-                               c->act_frame, c->act_ncell[o]);                                                                            \
+        if (actp) { if (wpb == 1) LAUNCH_EXT_W(NS, true, 1); else LAUNCH_EXT_W(NS, true, 4); }                                            \
+        else { if (wpb == 1) LAUNCH_EXT_W(NS, false, 1); else LAUNCH_EXT_W(NS, false, 4); }                                               \
     } while (0)
     switch (c->nspo) {
         case 1: LAUNCH_EXT(1); break;
@@ -741,6 +745,7 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
         default: LAUNCH_EXT(7); break;
     }
 #undef LAUNCH_EXT
+#undef LAUNCH_EXT_W
     HIP_TRY(hipGetLastError());
     t_end(c);
     return SIFTMI_OK;
