@@ -902,8 +902,9 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     // Large launches: ONE wavefront per workgroup (round 4).  Four independent wavefronts per workgroup held its LDS and wave slots
     // until the slowest was done; keypoints and descriptors differ 4x in window size.  Measured, 64 x 1080p: descriptors 1.20 -> 1.04 ms
     // on the benchmark frames, 6.46 -> 6.2 ms on dense texture (tools/dense_stage_times.py); the records do not depend on it.
-    int wpb_ori = 1, wpb_desc = 1;
+    int wpb_ori = 1, wpb_desc = 1, wg1 = 1024;                // workgroups per (frame, octave) group of the one-wavefront forms
 #ifdef SIFTMI_EXPERIMENT
+    if (const char *e = getenv("SIFTMI_EXP_KP_WG")) wg1 = atoi(e);
     if (const char *e = getenv("SIFTMI_EXP_ORI_WPB")) wpb_ori = atoi(e);
     if (const char *e = getenv("SIFTMI_EXP_DESC_WPB")) wpb_desc = atoi(e);
 #endif
@@ -911,7 +912,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
         hipLaunchKernelGGL((orientation_kernel<true, 4>), dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                            c->d_ori_angles);
     else if (wpb_ori == 1)
-        hipLaunchKernelGGL((orientation_kernel<false, 1>), dim3(1024, groups), dim3(64), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+        hipLaunchKernelGGL((orientation_kernel<false, 1>), dim3(wg1, groups), dim3(64), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                            c->d_ori_angles);
     else
         hipLaunchKernelGGL((orientation_kernel<false, 4>), dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
@@ -928,7 +929,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
                            c->d_desc_f32);
     else {
         if (wpb_desc == 1)
-            hipLaunchKernelGGL((descriptor_kernel<false, 1>), dim3(1024, groups), dim3(64), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+            hipLaunchKernelGGL((descriptor_kernel<false, 1>), dim3(wg1, groups), dim3(64), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                                c->d_desc_f32);
         else
             hipLaunchKernelGGL((descriptor_kernel<false, 4>), dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
