@@ -590,6 +590,12 @@ def test_match_ties_quirk_and_edges(sm):
     assert list(got["target"]) == [2, 2, 2]
     got = eng.match(_records(sm, lo), _records(sm, hi), 100.0, 100.0)
     np.testing.assert_allclose(got["distance"], np.sqrt(128.0), rtol=1e-6)
+    # ... in the other direction too (sources are packed as 127 - f, targets as f - 128: both corners of the int8 range), and mixed rows
+    got = eng.match(_records(sm, hi), _records(sm, lo), 100.0, 100.0)
+    np.testing.assert_allclose(got["distance"], np.sqrt(128.0), rtol=1e-6)
+    mix = np.tile(np.array([0, 255], np.int32), 64)[None, :]
+    ext = np.concatenate([lo[:1], hi[:1], mix, 255 - mix])
+    _assert_matches_equal(eng.match(_records(sm, ext), _records(sm, ext[::-1].copy()), 100.0, 100.0), pyoracle.match(ext, ext[::-1].copy(), 100.0, 100.0))
     # empty sides
     assert len(eng.match(_records(sm, lo), _records(sm, lo[:0]))) == 0
     assert len(eng.match(_records(sm, lo[:0]), _records(sm, lo))) == 0
