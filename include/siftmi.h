@@ -243,7 +243,13 @@ typedef struct siftmi_stream_config {
     int64_t kp_per_frame;               /* capacity of the packed outputs per frame (0 = 32768 / 49152)               */
     int64_t desc_per_frame;
     int32_t staging_buffers;            /* submit_host: device staging buffers (0 = as many as result sets)          */
-    int32_t reserved[7];
+    int32_t density_mode;               /* which of two equivalent launch sequences a step replays: 0 = chosen per step from the
+                                           descriptor totals of an earlier step (frames dense with keypoints run ONE chain without
+                                           the extrema scan's activity flags, sparse ones fork into per-octave chains with them);
+                                           1 = always the sparse form, 2 = always the dense form.  The records do not depend on it
+                                           (tests/test_gpu_parity.py::test_stream_density_hint_flip_is_byte_identical); only
+                                           siftmi_stats.raw_extrema[_exact] does, as count_raw_extrema describes */
+    int32_t reserved[6];
 } siftmi_stream_config;
 
 /* packed results of one step.  Device view: everything in HBM, nothing synchronised. */
@@ -264,8 +270,12 @@ typedef struct siftmi_step_host {
     const int32_t *counts;              /* [2][frames_per_step][n_octaves]                                            */
     int32_t n_keypoints, n_descriptors;
     int32_t overflow_flags;             /* != 0: a list was truncated (bits as siftmi_detect_describe_batch_device)   */
-    int32_t reserved;
+    int32_t launch_flags;               /* how this step was launched, SIFTMI_STEP_* bits (diagnostic; the records do not depend on it) */
 } siftmi_step_host;
+#define SIFTMI_STEP_DENSE_HINT   1      /* launched under the density hint: one chain, no activity flags, full extrema scan        */
+#define SIFTMI_STEP_GRAPH_REPLAY 2      /* the launch sequence came from a captured hipGraph (else: direct launches)                */
+#define SIFTMI_STEP_FORKED       4      /* ... which forks into per-octave chains                                                  */
+#define SIFTMI_STEP_RAW_EXACT    8      /* siftmi_stats.raw_extrema_exact of this step's context after the step                    */
 
 int  siftmi_stream_default_config(siftmi_stream_config *scfg, int32_t frames_per_step);
 /* ctx is borrowed (it stays the caller's and must outlive the stream); ctx->max_batch frames run in lock-step. */
@@ -298,6 +308,8 @@ int siftmi_stream_result_device(siftmi_stream *s, int back, siftmi_step_device *
 int siftmi_stream_result_host(siftmi_stream *s, int back, siftmi_step_host *out);
 /* everything submitted so far has finished (host blocks) */
 int siftmi_stream_synchronize(siftmi_stream *s);
+/* siftmi_stream_config.density_mode of the steps submitted from now on (0 automatic, 1 sparse form, 2 dense form) */
+int siftmi_stream_set_density_mode(siftmi_stream *s, int mode);
 
 /* ================================================================================================================
    Result exchange between the GPUs of a node: RCCL all-gather of every rank's packed results (the one exchange step
@@ -309,7 +321,14 @@ int siftmi_stream_synchronize(siftmi_stream *s);
    come from the totals of step k-1 (+ headroom), which are read on the host while step k runs: no host
    synchronisation between a step's kernels and its collectives.  If a rank's counts outgrow what was sent (a scene
    cut), the step is re-gathered in full by the NEXT siftmi_exchange_gather / siftmi_exchange_finish call, before its
-   result set can be reused; siftmi_exchange_result reports `complete`. */
+   result set can be reused; siftmi_exchange_result reports `complete`.
+
+   Failure: a collective completes only if every rank takes part.  No host wait of the exchange is unbounded: each polls its
+   event and the communicator's asynchronous error state until a deadline (SIFTMI_EXCHANGE_TIMEOUT_S seconds per wait, default
+   120; siftmi_exchange_set_timeout), then aborts the communicator (ncclCommAbort: collectives stuck on the device exit, the
+   streams ordered behind them drain) and returns SIFTMI_E_HIP with the rank and the step in siftmi_last_error().  An aborted
+   exchange fails every later call the same way; the caller ends the job (nothing is restarted).  The reference has no
+   counterpart: it drives one device (SIFT/SIFT.swift:139). */
 #define SIFTMI_UNIQUE_ID_BYTES 128
 typedef struct siftmi_exchange siftmi_exchange;
 
@@ -335,6 +354,14 @@ int  siftmi_exchange_unique_id(void *id /* SIFTMI_UNIQUE_ID_BYTES */);
 /* collective over the `world` ranks: ncclCommInitRank on the stream's device */
 int  siftmi_exchange_create(siftmi_stream *s, const void *unique_id, int rank, int world, siftmi_exchange **out);
 void siftmi_exchange_destroy(siftmi_exchange *x);
+/* what the communicator itself reports (ncclCommCount / ncclCommUserRank); siftmi_exchange_create has checked both against its
+   arguments */
+int  siftmi_exchange_ranks(siftmi_exchange *x, int32_t *comm_ranks, int32_t *comm_rank);
+/* deadline of every host wait of this exchange, in seconds (default: SIFTMI_EXCHANGE_TIMEOUT_S, else 120) */
+int  siftmi_exchange_set_timeout(siftmi_exchange *x, double seconds);
+/* host blocks, bounded as above, until every collective enqueued so far has finished (call it before a device-wide
+   synchronisation: that one has no deadline); not collective */
+int  siftmi_exchange_wait(siftmi_exchange *x);
 /* collective: all-gather the results of the last submitted step (side stream, no host synchronisation unless
    synchronous != 0, which sizes the payloads from this step's own totals) */
 int  siftmi_exchange_gather(siftmi_exchange *x, int synchronous);
@@ -350,7 +377,7 @@ int  siftmi_exchange_finish(siftmi_exchange *x, int64_t *regathered_steps, int64
 int  siftmi_exchange_set_headroom(siftmi_exchange *x, int32_t headroom_percent, int64_t quantum);
 /* accumulated GPU time of the gathers (side-stream hipEvents) and their number since creation; bytes received per gather */
 int  siftmi_exchange_stats(siftmi_exchange *x, double *ms, int64_t *gathers, int64_t *bytes_last);
-/* which library carries the collectives: the path / soname the seven ncclXxx entry points were resolved from (SIFTMI_RCCL_LIB
+/* which library carries the collectives: the path / soname the eleven ncclXxx entry points were resolved from (SIFTMI_RCCL_LIB
    if set, else an RCCL already mapped into the process, else librccl.so[.1]); "" if none could be loaded.  Loads it. */
 const char *siftmi_exchange_transport(void);
 
@@ -411,6 +438,11 @@ void siftmi_descriptor_to_reference(const siftmi_descriptor *in, int64_t n, sift
 
 /* --- introspection / parity hooks (state of the last detect/describe call) -------------------- */
 int siftmi_get_stats(siftmi_ctx *ctx, siftmi_stats *out);
+/* What the batched entry points (siftmi_detect_describe_batch[_device], the stream's submits) did with their launch sequences since
+   the context was created: sequences captured into a hipGraph, replayed from one, issued as direct launches (first sighting of a call
+   signature, graphs off, timings on).  last_flags: bit 0 the last sequence was a replay, bit 1 it was forked into per-octave chains,
+   bit 2 the context's density hint.  Any output may be NULL.  No reference counterpart (it has no launch graphs). */
+int siftmi_graph_stats(siftmi_ctx *ctx, int64_t *captures, int64_t *replays, int64_t *direct_sequences, int32_t *last_flags);
 int siftmi_octave_size(siftmi_ctx *ctx, int octave, int32_t *w, int32_t *h, float *delta);
 int siftmi_get_sigma(siftmi_ctx *ctx, int octave, int scale, float *sigma);
 int siftmi_get_weights(siftmi_ctx *ctx, int layer /*0 = seed, 1..nspo+2*/, float *weights, int32_t *count);

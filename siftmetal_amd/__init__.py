@@ -273,6 +273,13 @@ class Engine:
         out["raw_extrema_exact"] = bool(s.raw_extrema_exact)
         return out
 
+    def graph_stats(self):
+        """Launch sequences of the batched entry points since the context was created: captured / replayed / issued directly."""
+        a, b, c, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        _capi.check(self.L.siftmi_graph_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(f)))
+        return {"captures": int(a.value), "replays": int(b.value), "direct": int(c.value), "last_replayed": bool(f.value & 1),
+                "last_forked": bool(f.value & 2), "dense_hint": bool(f.value & 4)}
+
     def gaussian(self, o, s, frame=0):
         w, h, _ = self.octave_size(o)
         out = np.empty((h, w), np.float32)

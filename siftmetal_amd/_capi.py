@@ -22,9 +22,10 @@ EXPORTS = [
     "siftmi_device_alloc", "siftmi_device_free", "siftmi_memcpy", "siftmi_device_synchronize",
     "siftmi_stream_default_config", "siftmi_stream_create", "siftmi_stream_destroy", "siftmi_stream_context",
     "siftmi_stream_submit_device", "siftmi_stream_submit_host", "siftmi_stream_wait_upload", "siftmi_stream_wait_consumed",
-    "siftmi_stream_result_device", "siftmi_stream_result_host", "siftmi_stream_synchronize",
+    "siftmi_stream_result_device", "siftmi_stream_result_host", "siftmi_stream_synchronize", "siftmi_stream_set_density_mode",
     "siftmi_exchange_unique_id", "siftmi_exchange_create", "siftmi_exchange_destroy", "siftmi_exchange_gather",
     "siftmi_exchange_result", "siftmi_exchange_finish", "siftmi_exchange_stats", "siftmi_exchange_set_headroom", "siftmi_exchange_transport",
+    "siftmi_exchange_ranks", "siftmi_exchange_set_timeout", "siftmi_exchange_wait", "siftmi_graph_stats",
     "siftmi_gather_plan_init", "siftmi_gather_plan_resolve",
 ]
 NO_STREAM = C.c_void_p(-1).value          # SIFTMI_NO_STREAM
@@ -51,7 +52,8 @@ class Stats(C.Structure):
 
 class StreamConfig(C.Structure):         # siftmi_stream_config
     _fields_ = [("frames_per_step", C.c_int32), ("steps_in_flight", C.c_int32), ("result_sets", C.c_int32), ("format", C.c_int32),
-                ("kp_per_frame", C.c_int64), ("desc_per_frame", C.c_int64), ("staging_buffers", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("kp_per_frame", C.c_int64), ("desc_per_frame", C.c_int64), ("staging_buffers", C.c_int32), ("density_mode", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class StepDevice(C.Structure):           # siftmi_step_device
@@ -61,7 +63,10 @@ class StepDevice(C.Structure):           # siftmi_step_device
 
 class StepHost(C.Structure):             # siftmi_step_host
     _fields_ = [("step", C.c_int64), ("keypoints", C.c_void_p), ("descriptors", C.c_void_p), ("counts", C.POINTER(C.c_int32)),
-                ("n_keypoints", C.c_int32), ("n_descriptors", C.c_int32), ("overflow_flags", C.c_int32), ("reserved", C.c_int32)]
+                ("n_keypoints", C.c_int32), ("n_descriptors", C.c_int32), ("overflow_flags", C.c_int32), ("launch_flags", C.c_int32)]
+
+
+STEP_DENSE_HINT, STEP_GRAPH_REPLAY, STEP_FORKED, STEP_RAW_EXACT = 1, 2, 4, 8      # siftmi_step_host.launch_flags
 
 
 class Gathered(C.Structure):             # siftmi_gathered
@@ -165,6 +170,11 @@ def load():
     L.siftmi_stream_result_device.argtypes = [vp, C.c_int, C.POINTER(StepDevice), vp]
     L.siftmi_stream_result_host.argtypes = [vp, C.c_int, C.POINTER(StepHost)]
     L.siftmi_stream_synchronize.argtypes = [vp]
+    L.siftmi_stream_set_density_mode.argtypes = [vp, C.c_int]
+    L.siftmi_graph_stats.argtypes = [vp, i64p, i64p, i64p, i32p]
+    L.siftmi_exchange_ranks.argtypes = [vp, i32p, i32p]
+    L.siftmi_exchange_set_timeout.argtypes = [vp, C.c_double]
+    L.siftmi_exchange_wait.argtypes = [vp]
     L.siftmi_exchange_unique_id.argtypes = [vp]
     L.siftmi_exchange_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.siftmi_exchange_destroy.argtypes = [vp]

@@ -9,8 +9,17 @@
 //
 // librccl is loaded with dlopen at the first siftmi_exchange_* call: the library is 570 MB, single-GPU users never touch it,
 // and inside a process that already carries an RCCL (PyTorch bundles one) that copy is used instead of loading a second.
+//
+// Failure path (round 5).  A collective completes only if every rank takes part; a rank that died or hangs would leave the others
+// waiting inside hipEventSynchronize for ever (an 8-GPU job then ends when its lease does, with no output).  So no host wait in this
+// file is unbounded: exchange_wait() polls the event (hipEventQuery) and the communicator (ncclCommGetAsyncError) until a deadline
+// (SIFTMI_EXCHANGE_TIMEOUT_S, default 120 s per wait; siftmi_exchange_set_timeout), then aborts the communicator (ncclCommAbort makes
+// the collective kernels that are stuck on the device exit, so the streams ordered behind them drain) and returns SIFTMI_E_HIP naming
+// the rank and the step.  An aborted exchange fails every later call the same way; nothing is restarted.
 #pragma once
 #include <rccl/rccl.h>
+#include <chrono>
+#include <thread>
 
 struct RcclApi {
     void *handle = nullptr;
@@ -22,6 +31,10 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     bool ok = false;
     RcclApi() {
         const char *env = getenv("SIFTMI_RCCL_LIB");
@@ -39,7 +52,12 @@ struct RcclApi {
         GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
-        ok = GetUniqueId && CommInitRank && CommDestroy && AllGather && GroupStart && GroupEnd && GetErrorString;
+        CommCount = (decltype(CommCount))dlsym(handle, "ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))dlsym(handle, "ncclCommUserRank");
+        CommGetAsyncError = (decltype(CommGetAsyncError))dlsym(handle, "ncclCommGetAsyncError");
+        CommAbort = (decltype(CommAbort))dlsym(handle, "ncclCommAbort");
+        ok = GetUniqueId && CommInitRank && CommDestroy && AllGather && GroupStart && GroupEnd && GetErrorString && CommCount && CommUserRank &&
+             CommGetAsyncError && CommAbort;
     }
 };
 static const RcclApi &rccl() { static RcclApi api; return api; }
@@ -115,6 +133,11 @@ struct siftmi_exchange {
     siftmi_stream *s = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    int comm_ranks = 0, comm_rank = -1;           // what the communicator itself reports (ncclCommCount / ncclCommUserRank)
+    double timeout_s = 120.0;                     // deadline of every host wait (SIFTMI_EXCHANGE_TIMEOUT_S)
+    bool failed = false;                          // a wait expired or the communicator reported an error: aborted, every call fails
+    std::string fail_msg;
+    hipEvent_t ev_wait = nullptr;                 // siftmi_exchange_wait / finish / destroy: "everything enqueued so far"
     hipStream_t gstream = nullptr;
     GatherSet g[2];
     int cur = 1;                                  // index of the last gather's set
@@ -122,6 +145,58 @@ struct siftmi_exchange {
     int64_t regathered = 0, gathers = 0, bytes_last = 0;
     double ms = 0.0;
 };
+
+// the exchange is unusable from here on: stuck collectives are made to exit, later calls repeat the message
+static int exchange_fail(siftmi_exchange *x, const char *fmt, ...) {
+    char buf[400];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (!x->failed) {
+        x->failed = true;
+        x->fail_msg = buf;
+        if (x->comm) { (void)rccl().CommAbort(x->comm); x->comm = nullptr; }     // (frees the communicator: no ncclCommDestroy after it)
+    }
+    return set_error(SIFTMI_E_HIP, "%s", x->fail_msg.c_str());
+}
+static int exchange_check(siftmi_exchange *x) {
+    if (!x) return set_error(SIFTMI_E_BADARG, "null exchange");
+    if (x->failed) return set_error(SIFTMI_E_HIP, "exchange aborted earlier: %s", x->fail_msg.c_str());
+    return SIFTMI_OK;
+}
+// Bounded host wait for `ev` (an event recorded on the gather stream, or one a gather-stream operation feeds).
+static int exchange_wait(siftmi_exchange *x, hipEvent_t ev, const char *what, int64_t step) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned polls = 0;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return SIFTMI_OK;
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return exchange_fail(x, "rank %d of %d: hipEventQuery failed while waiting for %s of step %lld: %s", x->rank, x->world, what, (long long)step, hipGetErrorString(e));
+        }
+        (void)hipGetLastError();
+        if ((++polls & 63u) == 0 && x->comm) {
+            ncclResult_t async = ncclSuccess;
+            const ncclResult_t r = rccl().CommGetAsyncError(x->comm, &async);
+            if (r != ncclSuccess || (async != ncclSuccess && async != ncclInProgress))
+                return exchange_fail(x, "rank %d of %d: the communicator reported an asynchronous error while waiting for %s of step %lld: %s", x->rank, x->world, what,
+                                     (long long)step, rccl().GetErrorString(r != ncclSuccess ? r : async));
+        }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > x->timeout_s)
+            return exchange_fail(x, "rank %d of %d: timed out after %.1f s waiting for %s of step %lld (a rank died or hangs; SIFTMI_EXCHANGE_TIMEOUT_S); communicator aborted",
+                                 x->rank, x->world, waited, what, (long long)step);
+        if (polls < 200) std::this_thread::yield();                      // the usual wait is a few microseconds
+        else std::this_thread::sleep_for(std::chrono::microseconds(polls < 2000 ? 20 : 500));
+    }
+}
+// everything enqueued on the gather stream so far
+static int exchange_drain(siftmi_exchange *x, const char *what) {
+    HIP_TRY(hipEventRecord(x->ev_wait, x->gstream));
+    return exchange_wait(x, x->ev_wait, what, x->s ? x->s->step_no : -1);
+}
 
 extern "C" int siftmi_exchange_unique_id(void *id) {
     if (!id) return set_error(SIFTMI_E_BADARG, "null argument");
@@ -136,8 +211,11 @@ extern "C" int siftmi_exchange_unique_id(void *id) {
 extern "C" void siftmi_exchange_destroy(siftmi_exchange *x) {
     if (!x) return;
     (void)hipSetDevice(x->s->device);
-    if (x->gstream) (void)hipStreamSynchronize(x->gstream);
+    // a gather that can no longer complete (a peer is gone) must not hang the teardown: bounded, then aborted
+    if (x->gstream && x->ev_wait && !x->failed) (void)exchange_drain(x, "the pending gathers at destroy");
+    if (x->gstream && x->failed) (void)hipStreamSynchronize(x->gstream);          // aborted collectives exit
     if (x->comm) (void)rccl().CommDestroy(x->comm);
+    if (x->ev_wait) (void)hipEventDestroy(x->ev_wait);
     for (auto &g : x->g) {
         void *ptrs[] = {g.kp, g.desc, g.counts, g.totals};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -162,7 +240,9 @@ extern "C" int siftmi_exchange_create(siftmi_stream *s, const void *unique_id, i
     siftmi_exchange *x = new siftmi_exchange();
     x->s = s; x->rank = rank; x->world = world;
     siftmi_gather_plan_init(&x->plan, s->kp_cap, s->desc_cap);
+    if (const char *t = getenv("SIFTMI_EXCHANGE_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) x->timeout_s = v; }
     hipError_t e = hipStreamCreateWithFlags(&x->gstream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_wait, hipEventDisableTiming);
     const size_t n_counts = 2 * (size_t)s->F * s->n_oct;
     for (auto &g : x->g) {
         if (e == hipSuccess) e = hipMalloc((void **)&g.counts, (size_t)world * n_counts * sizeof(int32_t));
@@ -187,8 +267,36 @@ extern "C" int siftmi_exchange_create(siftmi_stream *s, const void *unique_id, i
         siftmi_exchange_destroy(x);
         return rc;
     }
+    // the communicator's own view of the job: a launcher that started fewer ranks than `world`, or two with one rank number, must not
+    // go unnoticed until the first collective hangs
+    ncclResult_t r1 = rccl().CommCount(x->comm, &x->comm_ranks), r2 = rccl().CommUserRank(x->comm, &x->comm_rank);
+    if (r1 != ncclSuccess || r2 != ncclSuccess || x->comm_ranks != world || x->comm_rank != rank) {
+        rc = set_error(SIFTMI_E_HIP, "communicator reports rank %d of %d, expected rank %d of %d [%s]", x->comm_rank, x->comm_ranks, rank, world, rccl().origin.c_str());
+        siftmi_exchange_destroy(x);
+        return rc;
+    }
     *out = x;
     return SIFTMI_OK;
+}
+
+extern "C" int siftmi_exchange_ranks(siftmi_exchange *x, int32_t *comm_ranks, int32_t *comm_rank) {
+    if (!x) return set_error(SIFTMI_E_BADARG, "null exchange");
+    if (comm_ranks) *comm_ranks = x->comm_ranks;
+    if (comm_rank) *comm_rank = x->comm_rank;
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_exchange_set_timeout(siftmi_exchange *x, double seconds) {
+    if (!x || !(seconds > 0.0)) return set_error(SIFTMI_E_BADARG, "bad argument");
+    x->timeout_s = seconds;
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_exchange_wait(siftmi_exchange *x) {
+    int rc = exchange_check(x);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(x->s->device));
+    return exchange_drain(x, "the gathers enqueued so far");
 }
 
 // A gathered set whose buffers are too small gets NEW blocks (1.5 x the need, so a growing scene does not reallocate every
@@ -218,9 +326,9 @@ static int grow_gather(siftmi_exchange *x, GatherSet &g, int64_t send_kp, int64_
 
 // the set is about to hold a new step: blocks it outgrew two gathers ago can go (every gather that wrote them has finished --
 // ev_done of the set -- and the window in which a consumer may hold their addresses is over)
-static int recycle_gather_set(GatherSet &g) {
+static int recycle_gather_set(siftmi_exchange *x, GatherSet &g) {
     if (g.retired.empty()) return SIFTMI_OK;
-    if (g.step >= 0) HIP_TRY(hipEventSynchronize(g.ev_done));
+    if (g.step >= 0) { const int rc = exchange_wait(x, g.ev_done, "the gather", g.step); if (rc) return rc; }
     for (void *p : g.retired) (void)hipFree(p);
     g.retired.clear();
     return SIFTMI_OK;
@@ -251,7 +359,7 @@ static int payload_gathers(siftmi_exchange *x, StreamResultSet &rs, GatherSet &g
 // totals of g's step are on the host: completeness, next sizes
 static int resolve_gather(siftmi_exchange *x, GatherSet &g) {
     if (g.step < 0 || g.resolved) return SIFTMI_OK;
-    HIP_TRY(hipEventSynchronize(g.ev_totals));
+    { const int rc = exchange_wait(x, g.ev_totals, "the totals all-gather", g.step); if (rc) return rc; }
     const int inc = siftmi_gather_plan_resolve(&x->plan, g.h_totals, x->world, g.sent_kp, g.sent_desc);
     if (inc < 0) return inc;
     g.resolved = true;
@@ -277,15 +385,19 @@ static int regather_if_needed(siftmi_exchange *x, GatherSet &g) {
     return SIFTMI_OK;
 }
 
-static void collect_time(siftmi_exchange *x, GatherSet &g) {
-    if (!g.timed) return;
-    float ms = 0.0f;
-    if (hipEventSynchronize(g.t1) == hipSuccess && hipEventElapsedTime(&ms, g.t0, g.t1) == hipSuccess) { x->ms += ms; x->gathers++; }
+static int collect_time(siftmi_exchange *x, GatherSet &g) {
+    if (!g.timed) return SIFTMI_OK;
     g.timed = false;
+    const int rc = exchange_wait(x, g.t1, "the gather", g.step);
+    if (rc) return rc;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, g.t0, g.t1) == hipSuccess) { x->ms += ms; x->gathers++; }
+    (void)hipGetLastError();
+    return SIFTMI_OK;
 }
 
 extern "C" int siftmi_exchange_gather(siftmi_exchange *x, int synchronous) {
-    if (!x) return set_error(SIFTMI_E_BADARG, "null exchange");
+    { const int rc0 = exchange_check(x); if (rc0) return rc0; }
     siftmi_stream *s = x->s;
     if (s->step_no < 0) return set_error(SIFTMI_E_STATE, "no step submitted yet");
     HIP_TRY(hipSetDevice(s->device));
@@ -295,8 +407,8 @@ extern "C" int siftmi_exchange_gather(siftmi_exchange *x, int synchronous) {
     GatherSet &g = x->g[x->cur ^ 1];
     int rc;
     // the set being recycled held the gather before the previous one: long finished; it was resolved when `prev` was issued
-    collect_time(x, g);
-    if ((rc = recycle_gather_set(g))) return rc;
+    if ((rc = collect_time(x, g))) return rc;
+    if ((rc = recycle_gather_set(x, g))) return rc;
     HIP_TRY(hipStreamWaitEvent(x->gstream, rs.ev_ready, 0));
     HIP_TRY(hipEventRecord(g.t0, x->gstream));
     RCCL_TRY(rccl().AllGather(rs.d_totals, g.totals, 4, ncclInt32, x->comm, x->gstream));
@@ -309,7 +421,7 @@ extern "C" int siftmi_exchange_gather(siftmi_exchange *x, int synchronous) {
     if ((rc = regather_if_needed(x, prev))) return rc;
     int64_t send_kp = x->plan.send_kp, send_desc = x->plan.send_desc;
     if (synchronous || send_kp < 0) {                      // first step (nothing to size from) or on request: this step's own totals
-        HIP_TRY(hipEventSynchronize(g.ev_totals));
+        if ((rc = exchange_wait(x, g.ev_totals, "the totals all-gather", g.step))) return rc;
         int64_t mk = 1, md = 1;
         for (int r = 0; r < x->world; r++) { mk = std::max<int64_t>(mk, g.h_totals[4 * r]); md = std::max<int64_t>(md, g.h_totals[4 * r + 1]); }
         send_kp = std::min(mk, s->kp_cap); send_desc = std::min(md, s->desc_cap);
@@ -326,15 +438,16 @@ extern "C" int siftmi_exchange_gather(siftmi_exchange *x, int synchronous) {
 
 extern "C" int siftmi_exchange_result(siftmi_exchange *x, int back, siftmi_gathered *out, void *consumer_stream, int wait_host) {
     if (!x || !out) return set_error(SIFTMI_E_BADARG, "null argument");
+    { const int rc0 = exchange_check(x); if (rc0) return rc0; }
     if (back < 0 || back > 1) return set_error(SIFTMI_E_BADARG, "back must be 0 or 1 (two gathered sets)");
     GatherSet &g = x->g[x->cur ^ back];
     if (g.step < 0) return set_error(SIFTMI_E_STATE, "no such gather yet");
     HIP_TRY(hipSetDevice(x->s->device));
     if (consumer_stream != SIFTMI_NO_STREAM) HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, g.ev_done, 0));
     if (wait_host) {
-        HIP_TRY(hipEventSynchronize(g.ev_done));
-        const int rc = resolve_gather(x, g);
+        int rc = exchange_wait(x, g.ev_done, "the gather", g.step);
         if (rc) return rc;
+        if ((rc = resolve_gather(x, g))) return rc;
     }
     memset(out, 0, sizeof(*out));
     out->step = g.step; out->world = x->world; out->complete = g.complete ? 1 : 0; out->resolved = g.resolved ? 1 : 0;
@@ -345,16 +458,16 @@ extern "C" int siftmi_exchange_result(siftmi_exchange *x, int back, siftmi_gathe
 }
 
 extern "C" int siftmi_exchange_finish(siftmi_exchange *x, int64_t *regathered_steps, int64_t *overflow_steps) {
-    if (!x) return set_error(SIFTMI_E_BADARG, "null exchange");
+    int rc = exchange_check(x);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(x->s->device));
-    int rc;
     for (int b = 1; b >= 0; b--) {
         GatherSet &g = x->g[x->cur ^ b];
         if ((rc = resolve_gather(x, g))) return rc;
         if ((rc = regather_if_needed(x, g))) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(x->gstream));
-    collect_time(x, x->g[0]); collect_time(x, x->g[1]);
+    if ((rc = exchange_drain(x, "the last gathers (finish)"))) return rc;
+    if ((rc = collect_time(x, x->g[0])) || (rc = collect_time(x, x->g[1]))) return rc;
     if (regathered_steps) *regathered_steps = x->regathered;
     if (overflow_steps) *overflow_steps = x->plan.steps_overflowed;
     return SIFTMI_OK;

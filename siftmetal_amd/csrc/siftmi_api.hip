@@ -80,9 +80,9 @@ struct StageRange {                            // host-side range around the lau
 // onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and a forked launch graph of four octave chains occupies all of
 // them: a copy stream that shares a queue with a chain has its barrier packets queued behind that chain's kernels, and the upload
 // of sub-batch i + 1 then starts when sub-batch i has FINISHED instead of under it (round 4: 64 x 1080p through 16-frame sub-batches
-// 19.7 ms forked against 14.8 ms with the serial graph).  Streams of another priority get hardware queues of their own, so the
-// copy streams are created at the highest priority -- they launch no kernels, so they take no CUs from anybody.
-// SIFTMI_COPY_STREAM_PRIORITY=0 restores plain streams.
+// 19.7 ms forked against 14.8 ms with the serial graph).  Streams of another priority get hardware queues of their own; creating the
+// copy streams at the highest priority is OFF by default (measured: 16.4-16.7 ms forked with it, still behind one chain, and nothing
+// for the frame stream's host-fed step), SIFTMI_COPY_STREAM_PRIORITY=1 turns it on.  What ships: host-fed sub-batches stay one chain.
 static hipError_t create_copy_stream(hipStream_t *s) {
     static const int mode = [] { const char *e = getenv("SIFTMI_COPY_STREAM_PRIORITY"); return e ? atoi(e) : 0; }();
     int least = 0, greatest = 0;
@@ -198,7 +198,11 @@ struct siftmi_ctx {
     std::vector<GraphEntry> gcache;
     std::vector<GraphKey> gseen;               // signatures seen once (not yet captured), oldest first
     static constexpr size_t GCACHE_MAX = 64;
+    size_t graph_min_cap = 0;                  // a host-fed call of n sub-batches needs n signatures alive at once (siftmi_detect_describe_batch)
     bool graph_failed = false;
+    // what the batched entry points did with their launch sequences (siftmi_graph_stats): captured, replayed, issued as direct launches
+    int64_t n_graph_captures = 0, n_graph_replays = 0, n_direct_sequences = 0;
+    bool last_replayed = false, last_forked = false;   // the last sequence: came from a captured graph / forked into per-octave chains
     // fork/join of the octave chains inside a captured graph (small launches only, see run_dense_detect)
     hipStream_t oct_stream[MAX_OCT] = {};
     hipEvent_t ev_fork[MAX_OCT] = {}, ev_join[MAX_OCT] = {};
@@ -543,7 +547,11 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
         // with 544-row chunks, R = 5 / 7 / 8 792 / 817 / 921 -> 819 / 840 / 948; octave 1 R = 10 / 13 262 / 250 -> 244 / 241 us).
         if (R >= 9) {
             const long long total_long = (long long)((w + Gr::TW - 1) / Gr::TW) * ((h + 543) / 544) * nf;
-            if (total_long >= 1536 && getenv("SIFTMI_EXP_CHUNK_BIG") == nullptr && getenv("SIFTMI_EXP_CHUNK_SMALL") == nullptr) chr = 544;
+            bool long_ok = total_long >= 1536;
+#ifdef SIFTMI_EXPERIMENT
+            long_ok = long_ok && getenv("SIFTMI_EXP_CHUNK_BIG") == nullptr && getenv("SIFTMI_EXP_CHUNK_SMALL") == nullptr;
+#endif
+            if (long_ok) chr = 544;
         }
         const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
         if (uses_march(c, w, h, nf)) {
@@ -975,9 +983,13 @@ static size_t graph_cache_max() {                             // SIFTMI_GRAPH_CA
     static const size_t n = [] {
         const char *e = getenv("SIFTMI_GRAPH_CACHE");
         const int v = e ? atoi(e) : 0;
-        return (size_t)((v >= 1 && v <= (int)siftmi_ctx::GCACHE_MAX) ? v : (int)siftmi_ctx::GCACHE_MAX);
+        return (size_t)((v >= 1 && v <= (int)siftmi_ctx::GCACHE_MAX) ? v : 0);
     }();
-    return n;
+    return n;                                                 // 0: no override
+}
+static size_t graph_cache_cap(const siftmi_ctx *c) {
+    const size_t forced = graph_cache_max();
+    return forced ? forced : std::max(siftmi_ctx::GCACHE_MAX, c->graph_min_cap);
 }
 static void retire_exec(hipGraphExec_t exec) {
     if (exec && graph_destroy_safe()) (void)hipGraphExecDestroy(exec);
@@ -1059,7 +1071,9 @@ static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::Gr
     bool seen = false;
     for (const auto &k : c->gseen) seen = seen || k == key;
     if (!seen) {
-        if (c->gseen.size() >= 16) c->gseen.erase(c->gseen.begin());
+        // (as many candidates as graphs may be cached: a call of n sub-batches shows n signatures before the first repeats; with 16
+        // entries round 4's 64-frame host-fed call at max_batch 8 evicted every signature before its second sighting -- ADVICE r4)
+        if (c->gseen.size() >= graph_cache_cap(c)) c->gseen.erase(c->gseen.begin());
         c->gseen.push_back(key);
     }
     for (size_t i = 0; i < c->gcache.size(); i++)
@@ -1077,7 +1091,7 @@ static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::Gr
     // caller whose buffers keep changing would leak without bound.  There the cache simply stops growing and new signatures
     // run as direct launches (round 2's behaviour).
     bool may_capture = seen;
-    if (!exec && seen && c->gcache.size() >= graph_cache_max()) {
+    if (!exec && seen && c->gcache.size() >= graph_cache_cap(c)) {
         if (graph_destroy_safe()) {
             (void)hipDeviceSynchronize();                  // it may still be running
             retire_exec(c->gcache.front().exec);
@@ -1105,12 +1119,15 @@ static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::Gr
             bool seq_exact = true;
             for (int o = 0; o < c->n_oct; o++) seq_exact = seq_exact && !c->act_valid[o];
             c->gcache.push_back(siftmi_ctx::GraphEntry{key, exec, seq_exact});
+            c->n_graph_captures++;
         }
     }
     if (exec) {
         StageRange rg("siftmi graph replay (detect+describe batch)");
         HIP_TRY(hipGraphLaunch(exec, st));
         *launched = true;
+        c->n_graph_replays++;
+        c->last_replayed = true; c->last_forked = key.fork;
     }
     return SIFTMI_OK;
 }
@@ -1138,7 +1155,11 @@ extern "C" int siftmi_detect_describe_batch_device(siftmi_ctx *c, int32_t n_fram
     bool launched = false;
     if ((rc = replay_or_capture(c, st, key, enqueue, &launched))) return rc;
     if (launched) c->last_sub_frames = std::min(c->B, n_frames - ((n_frames - 1) / c->B) * c->B);
-    else if ((rc = enqueue(false))) return rc;
+    else {
+        if ((rc = enqueue(false))) return rc;
+        c->n_direct_sequences++;
+        c->last_replayed = false; c->last_forked = false;
+    }
     c->last_frames = n_frames;
     c->pyramid_valid = true;
     return order_end(c, st);
@@ -1251,6 +1272,11 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     // memory through 16-frame sub-batches, 4 + 16 + 16 + 16 + 12 instead of 4 x 16.
     const int first_nf = (!on_device && n_frames > c->B && c->B >= 4) ? c->B / 4 : c->B;
     const int n_sub = first_nf < c->B ? 1 + (n_frames - first_nf + c->B - 1) / c->B : (n_frames + c->B - 1) / c->B;
+    // The launch sequence of sub-batch i is keyed by its staging slot, so a call must start on the same slot every time or an odd
+    // sub-batch count doubles the signatures of a call shape (9 sub-batches x 2 slots cycling through a 16-entry candidate
+    // list were never captured).  The previous host call has synchronised, both slots are free (and ev_consumed still orders them).
+    c->input_slot = 0;
+    c->graph_min_cap = std::max(c->graph_min_cap, (size_t)n_sub + 8);
     HIP_TRY(c->h_sub.resize(4 * (size_t)n_sub));
     HIP_TRY(c->h_kp.resize(1)); HIP_TRY(c->h_desc.resize(1));          // (callers get non-null pointers for empty results too)
     while ((int)c->ev_sub.size() < n_sub) {
@@ -1301,7 +1327,11 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
 #endif
         auto enqueue_g = [&](bool fork) { return enqueue(fork && (on_device != 0 || host_fork)); };
         if ((rc = replay_or_capture(c, st, key, enqueue_g, &launched))) return rc;
-        if (!launched && (rc = enqueue(false))) return rc;
+        if (!launched) {
+            if ((rc = enqueue(false))) return rc;
+            c->n_direct_sequences++;
+            c->last_replayed = false; c->last_forked = false;
+        }
         if ((rc = input_consumed(c, on_device))) return rc;
         // the running totals after this sub-batch: its packed records are final from here on
         HIP_TRY(hipMemcpyAsync(c->h_sub.data() + 4 * sub, c->d_state, sizeof(PackState), hipMemcpyDeviceToHost, st));
@@ -1717,6 +1747,15 @@ extern "C" int siftmi_get_stats(siftmi_ctx *c, siftmi_stats *out) {
     out->n_frames = c->last_frames; out->n_octaves = c->n_oct;
     out->raw_extrema = c->h_stats.data(); out->candidates = c->h_stats.data() + ng; out->keypoints = c->h_stats.data() + 2 * ng;
     out->oriented = c->h_stats.data() + 3 * ng; out->descriptors = c->h_stats.data() + 4 * ng;
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_graph_stats(siftmi_ctx *c, int64_t *captures, int64_t *replays, int64_t *direct_sequences, int32_t *last_flags) {
+    if (!c) return set_error(SIFTMI_E_BADARG, "null ctx");
+    if (captures) *captures = c->n_graph_captures;
+    if (replays) *replays = c->n_graph_replays;
+    if (direct_sequences) *direct_sequences = c->n_direct_sequences;
+    if (last_flags) *last_flags = (c->last_replayed ? 1 : 0) | (c->last_forked ? 2 : 0) | (c->dense_hint ? 4 : 0);
     return SIFTMI_OK;
 }
 

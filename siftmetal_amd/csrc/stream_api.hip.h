@@ -28,6 +28,7 @@ struct StreamResultSet {
     bool tot_rec = false;
     bool ready_rec = false, d2h_rec = false, gather_rec = false;
     int64_t step = -1;                        // the step this set holds
+    int32_t launch_flags = 0;                 // how the step was launched (siftmi_step_host.launch_flags)
     int64_t spec_kp = 0, spec_desc = 0;       // records covered by the copy started at submit time
     bool host_done = false;                   // siftmi_stream_result_host has completed for `step`
     int32_t nk = 0, nd = 0, flags = 0;
@@ -54,6 +55,7 @@ struct siftmi_stream {
     // (a siftmi_stream_result_host call since the previous submit); a consumer of the device views pays nothing
     bool host_reader = false;
     bool dense = false;                       // the density hint, from the last totals seen (applied to the step's context at submit)
+    int density_mode = 0;                     // siftmi_stream_config.density_mode
     int64_t spec_kp = 0, spec_desc = 0;
 };
 
@@ -136,6 +138,7 @@ extern "C" int siftmi_stream_create(siftmi_ctx *ctx, const siftmi_stream_config 
         return set_error(SIFTMI_E_BADARG, "unknown pixel format %d", scfg->format);
     if (scfg->kp_per_frame < 0 || scfg->desc_per_frame < 0 || scfg->staging_buffers < 0 || scfg->staging_buffers > 64)
         return set_error(SIFTMI_E_BADARG, "negative capacity / bad staging_buffers");
+    if (scfg->density_mode < 0 || scfg->density_mode > 2) return set_error(SIFTMI_E_BADARG, "density_mode %d out of range [0, 2]", scfg->density_mode);
     HIP_TRY(hipSetDevice(ctx->device));
     siftmi_stream *s = new siftmi_stream();
     s->scfg = *scfg;
@@ -143,6 +146,7 @@ extern "C" int siftmi_stream_create(siftmi_ctx *ctx, const siftmi_stream_config 
     s->n_ctx = scfg->steps_in_flight;
     s->F = scfg->frames_per_step;
     s->n_oct = ctx->n_oct;
+    s->density_mode = scfg->density_mode;
     // a multiple of the number of contexts, so that a context always meets the same result sets: the library replays a
     // captured launch sequence per (input, output, stream) signature, and every new pairing would be captured afresh
     int n_sets = scfg->result_sets > 0 ? scfg->result_sets : 2 * s->n_ctx;
@@ -237,13 +241,17 @@ static int submit_step(siftmi_stream *s, const void *d_pixels, size_t row_stride
     // Density hint for the launch graph (siftmi_ctx::dense_hint): the descriptor total of the most recent step whose totals have
     // reached the host -- no wait, a few steps late at most.  Above ~1e4 descriptors per 1080p frame (4.8e-3 per input pixel) the
     // one-chain sequence is the faster one (tools/fork_density_sweep.py, bench.py config.dense), below it the forked one.
-    for (int back = 1; back <= s->n_sets && back <= k; back++) {
+    // The hint only selects between launch sequences that compute the same records (one chain without activity flags / forked with
+    // them); WHICH one a step gets depends on when totals happen to arrive, so it is reported per step (siftmi_step_host.launch_flags)
+    // and can be pinned (siftmi_stream_config.density_mode, siftmi_stream_set_density_mode).
+    for (int back = 1; s->density_mode == 0 && back <= s->n_sets && back <= k; back++) {
         StreamResultSet &prev = s->sets[(size_t)((k - back) % s->n_sets)];
         if (prev.step != k - back || !prev.tot_rec || hipEventQuery(prev.ev_tot) != hipSuccess) continue;
         const double per_px = (double)prev.h_tot[1] / ((double)s->F * s->ctx[0]->cfg.width * s->ctx[0]->cfg.height);
         s->dense = per_px > 4.8e-3;
         break;
     }
+    if (s->density_mode) s->dense = s->density_mode == 2;
     s->ctx[ci]->dense_hint = s->dense;
     (void)hipGetLastError();                                  // (hipEventQuery's hipErrorNotReady is not an error)
     const int rc = siftmi_detect_describe_batch_device(s->ctx[ci], s->F, d_pixels, s->scfg.format, row_stride, frame_stride, (siftmi_keypoint *)rs.d_kp,
@@ -252,6 +260,8 @@ static int submit_step(siftmi_stream *s, const void *d_pixels, size_t row_stride
     // the step is launched: commit its bookkeeping first (events recorded on a healthy stream do not fail; if one does, the
     // state still says "this set / slot belongs to step k")
     rs.step = k; rs.host_done = false; rs.spec_kp = rs.spec_desc = 0;
+    rs.launch_flags = (s->ctx[ci]->dense_hint ? SIFTMI_STEP_DENSE_HINT : 0) | (s->ctx[ci]->last_replayed ? SIFTMI_STEP_GRAPH_REPLAY : 0) |
+                      (s->ctx[ci]->last_forked ? SIFTMI_STEP_FORKED : 0) | (s->ctx[ci]->raw_exact ? SIFTMI_STEP_RAW_EXACT : 0);
     rs.gather_rec = false; rs.d2h_rec = false;
     s->step_no = k;
     if (step) *step = k;
@@ -411,9 +421,15 @@ extern "C" int siftmi_stream_result_host(siftmi_stream *s, int back, siftmi_step
     out->step = rs.step;
     out->keypoints = rs.h_kp.data(); out->descriptors = rs.h_desc.data();
     out->counts = rs.h_meta + 4;
-    out->n_keypoints = rs.nk; out->n_descriptors = rs.nd; out->overflow_flags = rs.flags; out->reserved = 0;
+    out->n_keypoints = rs.nk; out->n_descriptors = rs.nd; out->overflow_flags = rs.flags; out->launch_flags = rs.launch_flags;
     if (rs.flags & 32) return set_error(SIFTMI_E_BADARG, "step %lld: SIFTMI_FMT_GRAYF32 frame with a value outside [0, 1] (include/siftmi.h, siftmi_format)", (long long)rs.step);
     if (rs.flags) return set_error(SIFTMI_E_CAPACITY, "list capacity exceeded in step %lld (overflow flags 0x%x): results truncated", (long long)rs.step, rs.flags);
+    return SIFTMI_OK;
+}
+
+extern "C" int siftmi_stream_set_density_mode(siftmi_stream *s, int mode) {
+    if (!s || mode < 0 || mode > 2) return set_error(SIFTMI_E_BADARG, "bad argument");
+    s->density_mode = mode;
     return SIFTMI_OK;
 }
 

@@ -112,6 +112,20 @@ class Exchange:
         _capi.check(_capi.load().siftmi_exchange_unique_id(buf))
         return bytes(buf)
 
+    def ranks(self):
+        """(ranks, this rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int32(), C.c_int32()
+        _capi.check(self.L.siftmi_exchange_ranks(self.h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
+    def set_timeout(self, seconds):
+        """Deadline of every host wait of the exchange; on expiry the communicator is aborted and the call raises."""
+        _capi.check(self.L.siftmi_exchange_set_timeout(self.h, float(seconds)))
+
+    def wait(self):
+        """Bounded host wait for every collective enqueued so far (call before an unbounded device synchronisation)."""
+        _capi.check(self.L.siftmi_exchange_wait(self.h))
+
     def set_headroom(self, percent, quantum=1024):
         _capi.check(self.L.siftmi_exchange_set_headroom(self.h, int(percent), int(quantum)))
 
@@ -164,8 +178,9 @@ class FrameStream:
     """siftmi_stream_* on one GPU.  pipeline = steps in flight (contexts); result_sets rotating output buffer sets."""
 
     def __init__(self, engine, frames_per_step, device=None, world_size=1, kp_per_frame=32768, desc_per_frame=49152, overlap_gather=False,
-                 pipeline=1, result_sets=None, fmt=_capi.FMT_BGRA8, rank=0, unique_id=None):
+                 pipeline=1, result_sets=None, fmt=_capi.FMT_BGRA8, rank=0, unique_id=None, density_mode=0):
         assert 1 <= pipeline <= 4
+        self._density_mode = density_mode
         self.L = _capi.load()
         self.eng, self.F, self.pipeline = engine, frames_per_step, pipeline
         self.n_octaves = engine.n_octaves
@@ -183,6 +198,7 @@ class FrameStream:
         _capi.check(self.L.siftmi_stream_default_config(C.byref(scfg), self.F))
         scfg.steps_in_flight, scfg.result_sets, scfg.format = self.pipeline, self._result_sets, fmt
         scfg.kp_per_frame, scfg.desc_per_frame = self._kp_per_frame, self._desc_per_frame
+        scfg.density_mode = self._density_mode
         h = C.c_void_p()
         _capi.check(self.L.siftmi_stream_create(self.eng.h, C.byref(scfg), C.byref(h)))
         self.h, self.fmt = h, fmt
@@ -273,6 +289,12 @@ class FrameStream:
     def synchronize(self):
         _capi.check(self.L.siftmi_stream_synchronize(self.h))
 
+    def set_density_mode(self, mode):
+        """0: the launch sequence of a step is chosen from earlier steps' descriptor totals; 1: always the sparse form (forked,
+        activity flags); 2: always the dense form (one chain, full extrema scan).  The records do not depend on it."""
+        _capi.check(self.L.siftmi_stream_set_density_mode(self.h, int(mode)))
+        self._density_mode = int(mode)
+
     def all_gather(self, synchronous=False):
         """RCCL all-gather of the last step's packed results on the exchange's side stream (siftmi_exchange_gather): payload
         sizes from the previous step's counts, no host synchronisation; a step that turns out to have been cut short is
@@ -299,4 +321,4 @@ class FrameStream:
         if copy:
             kp, ds, counts = kp.copy(), ds.copy(), counts.copy()
         return {"step": int(r.step), "n_keypoints": nk, "n_descriptors": nd, "keypoints": kp, "descriptors": ds, "counts": counts,
-                "overflow_flags": int(r.overflow_flags)}
+                "overflow_flags": int(r.overflow_flags), "launch_flags": int(r.launch_flags)}

@@ -6,6 +6,8 @@
  *     scenario    "plain"            every step the small set
  *                 "jump:K:R"         rank R runs its large set at step K (a > 25 % count jump on ONE rank only)
  *                 "overflow:R"       rank R's context has tiny keypoint lists (list overflow on one rank, every step)
+ *                 "die:K:R"          rank R kills itself (SIGKILL) after submitting step K, before its gather: the others must come
+ *                                    back with an error inside SIFTMI_EXCHANGE_TIMEOUT_S instead of hanging (exit code 3)
  *     pipeline    steps in flight (1 or 2); result sets = 2 x pipeline
  *     synchronous 1: siftmi_exchange_gather(x, 1) sizes every step from its own totals (host sync); 0: from the previous step
  *     idfile      rank 0 writes the unique id there (atomic rename), the others wait for it
@@ -15,7 +17,9 @@
  *                   int32 world, complete_at_first_look, complete_when_read, 0; int64 kp_records, desc_records
  *                   per rank r: int32 totals[4]; counts (n_counts); min(totals[0], kp_records) x 44 B; min(totals[1], desc_records) x 136 B
  *                 trailer: int64 -1; int64 regathered_steps, overflow_steps, gathers, bytes_last
- * Exit codes: 0 ok, 77 the transport refused this layout (real RCCL with two ranks on one GPU), anything else a failure. */
+ * Exit codes: 0 ok, 3 the exchange timed out / was aborted (a peer is gone), 77 the transport refused this layout (real RCCL with
+ * two ranks on one GPU), anything else a failure. */
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,7 +31,10 @@
 #define CHECK(expr)                                                                                         \
     do {                                                                                                    \
         int rc_ = (expr);                                                                                   \
-        if (rc_ != SIFTMI_OK) { fprintf(stderr, "rank %d: %s -> %d: %s\n", g_rank, #expr, rc_, siftmi_last_error()); return 2; } \
+        if (rc_ != SIFTMI_OK) {                                                                             \
+            fprintf(stderr, "rank %d: %s -> %d: %s\n", g_rank, #expr, rc_, siftmi_last_error());            \
+            return (strstr(siftmi_last_error(), "timed out") || strstr(siftmi_last_error(), "aborted")) ? 3 : 2; \
+        }                                                                                                   \
     } while (0)
 
 static int g_rank = 0;
@@ -80,8 +87,9 @@ int main(int argc, char **argv) {
     const char *idfile = argv[11];
     const size_t set_bytes = (size_t)F * H * W * 4;
     g_rank = rank;
-    int jump_step = -1, jump_rank = -1, overflow_rank = -1;
+    int jump_step = -1, jump_rank = -1, overflow_rank = -1, die_step = -1, die_rank = -1;
     if (sscanf(scenario, "jump:%d:%d", &jump_step, &jump_rank) == 2) {}
+    else if (sscanf(scenario, "die:%d:%d", &die_step, &die_rank) == 2) {}
     else if (sscanf(scenario, "overflow:%d", &overflow_rank) == 1) {}
     else if (strcmp(scenario, "plain") != 0) { fprintf(stderr, "unknown scenario %s\n", scenario); return 1; }
 
@@ -126,6 +134,11 @@ int main(int argc, char **argv) {
         return strstr(siftmi_last_error(), "ncclCommInitRank") ? 77 : 2;   /* the transport refused (real RCCL: duplicate GPU) */
     }
     CHECK(siftmi_exchange_set_headroom(x, 25, 16));
+    {
+        int32_t cr = -1, cn = -1;
+        CHECK(siftmi_exchange_ranks(x, &cn, &cr));
+        if (cn != world || cr != rank) { fprintf(stderr, "rank %d: communicator says rank %d of %d\n", rank, cr, cn); return 6; }
+    }
 
     FILE *fin = fopen(argv[12], "rb");
     if (!fin) { perror(argv[12]); return 1; }
@@ -150,6 +163,11 @@ int main(int argc, char **argv) {
         const int big = (k == jump_step && rank == jump_rank);
         CHECK(siftmi_stream_submit_device(st, d_sets[big], (size_t)W * 4, (size_t)W * H * 4, SIFTMI_NO_STREAM, &step));
         if (step != k) { fprintf(stderr, "step number %lld, expected %d\n", (long long)step, k); return 4; }
+        if (k == die_step && rank == die_rank) {                            /* gone without a word: no teardown, no message to the peers */
+            fprintf(stderr, "rank %d: dying at step %d\n", rank, k);
+            fflush(stderr);
+            raise(SIGKILL);
+        }
         CHECK(siftmi_exchange_gather(x, synchronous));
         if (k >= 1) {                                                      /* step k-1, while step k runs: own results, then every rank's row */
             rc = siftmi_stream_result_host(st, 1, &r);

@@ -1,7 +1,7 @@
 /* fake_rccl.c -- a TEST transport with librccl's entry points, for running the library's result exchange
  * (siftmetal_amd/csrc/exchange_api.hip.h: siftmi_exchange_*) with several ranks on ONE GPU.
  *
- * libsiftmi.so resolves seven RCCL symbols from the library named by SIFTMI_RCCL_LIB.  This file implements exactly those over
+ * libsiftmi.so resolves eleven RCCL symbols from the library named by SIFTMI_RCCL_LIB.  This file implements exactly those over
  * POSIX shared memory between processes that share a device (real RCCL refuses two ranks on one GPU), with the stream
  * semantics the exchange relies on: every call is enqueued on the caller's stream and returns at once; the data moves when the
  * stream gets there; ranks meet per collective.  It is test infrastructure (tests/test_gpu_parity.py::test_exchange_*_ranks_*,
@@ -14,6 +14,9 @@
  *      buffer, mark seq consumed
  *   3. hipMemcpyAsync  bounce buffer row r -> recv + r * n + offset, for every rank r     (host to device)
  * All waits time out (FAKE_RCCL_TIMEOUT_S, default 120 s) and poison the communicator instead of hanging a GPU box.
+ * Like RCCL, a collective whose peer never arrives does not complete by itself: the library's own deadline (exchange_api.hip.h,
+ * SIFTMI_EXCHANGE_TIMEOUT_S) calls ncclCommAbort, which here makes this rank's pending host functions return at once
+ * (tests/test_exchange_ranks.py::test_exchange_rank_dies_and_the_others_abort_within_the_deadline).
  * ncclGroupStart / ncclGroupEnd are accepted and ignored: every rank issues the same calls in the same order (the contract of a
  * real group too), so running them one after the other is an allowed schedule.  One stream at a time per communicator is ordered
  * by an event when the stream changes. */
@@ -34,7 +37,8 @@
 #include <unistd.h>
 
 /* the slice of rccl.h this transport implements (values as in RCCL 2.x) */
-typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5 } ncclResult_t;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5,
+               ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
 typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8, ncclBfloat16 = 9 } ncclDataType_t;
 #define NCCL_UNIQUE_ID_BYTES 128
 typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
@@ -63,6 +67,7 @@ struct fakeComm {
     hipEvent_t last_ev;
     int have_last;
     double timeout_s;
+    _Atomic int32_t aborted;     /* ncclCommAbort on THIS rank: its pending host functions return at once */
 };
 typedef struct fakeComm *ncclComm_t;
 
@@ -92,6 +97,7 @@ static int wait_all(struct fakeComm *c, _Atomic uint64_t *arr, uint64_t want, co
             if (atomic_load_explicit(&arr[r], memory_order_acquire) < want) { ok = 0; break; }
         if (ok) return 0;
         if (atomic_load_explicit(&c->hdr->poisoned, memory_order_acquire)) return 1;
+        if (atomic_load_explicit(&c->aborted, memory_order_acquire)) return 1;
         if ((++spins & 1023u) == 0) {
             if (now_s() - t0 > c->timeout_s) {
                 fprintf(stderr, "fake_rccl: rank %d timed out after %.0f s waiting for %s %llu\n", c->rank, c->timeout_s, what, (unsigned long long)want);
@@ -128,6 +134,8 @@ const char *ncclGetErrorString(ncclResult_t r) {
     case ncclInternalError: return "internal error (fake_rccl)";
     case ncclInvalidArgument: return "invalid argument (fake_rccl)";
     case ncclInvalidUsage: return "invalid usage (fake_rccl)";
+    case ncclRemoteError: return "remote error (fake_rccl)";
+    case ncclInProgress: return "in progress (fake_rccl)";
     }
     return "unknown result (fake_rccl)";
 }
@@ -214,6 +222,33 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int r
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t c, int *count) {
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->world;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int *rank) {
+    if (!c || !rank) return ncclInvalidArgument;
+    *rank = c->rank;
+    return ncclSuccess;
+}
+
+/* a wait that timed out inside the transport (any rank) is this communicator's asynchronous error */
+ncclResult_t ncclCommGetAsyncError(ncclComm_t c, ncclResult_t *async_error) {
+    if (!c || !async_error) return ncclInvalidArgument;
+    *async_error = atomic_load(&c->hdr->poisoned) ? ncclSystemError : ncclSuccess;
+    return ncclSuccess;
+}
+
+/* Stuck collectives give up (this rank's host functions stop waiting, the stream drains with garbage in the receive buffers), then
+ * the communicator is freed.  The shared header is left alone: the other ranks find out by their own deadlines, as with RCCL. */
+ncclResult_t ncclCommAbort(ncclComm_t c) {
+    if (!c) return ncclSuccess;
+    atomic_store_explicit(&c->aborted, 1, memory_order_release);
+    return ncclCommDestroy(c);
+}
+
 ncclResult_t ncclGroupStart(void) { return ncclSuccess; }
 ncclResult_t ncclGroupEnd(void) { return ncclSuccess; }
 
@@ -231,7 +266,7 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     if (!c || !send || !recv) return ncclInvalidArgument;
     const size_t es = dtype_bytes(dtype);
     if (!es) return ncclInvalidArgument;
-    if (atomic_load(&c->hdr->poisoned)) return ncclSystemError;
+    if (atomic_load(&c->hdr->poisoned) || atomic_load(&c->aborted)) return ncclSystemError;
     const size_t n = count * es;
     if (c->have_last && c->last_stream != stream) {            /* the bounce buffers are shared: order the streams */
         if (hipStreamWaitEvent(stream, c->last_ev, 0) != hipSuccess) return ncclUnhandledCudaError;

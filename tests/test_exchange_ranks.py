@@ -21,11 +21,12 @@ FAKE = os.path.join(CDIR, "libfake_rccl.so")
 EXE = os.path.join(CDIR, "exchange_ranks")
 W, H, N_OCT, F = 640, 480, 3, 2
 
-RCCL_SYMBOLS = ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString")
+RCCL_SYMBOLS = ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString",
+                "ncclCommCount", "ncclCommUserRank", "ncclCommGetAsyncError", "ncclCommAbort")
 
 
 def test_test_transport_exports_what_the_exchange_resolves():
-    """CPU: libfake_rccl.so is built by __graft_entry__.build() and carries the seven symbols exchange_api.hip.h looks up."""
+    """CPU: libfake_rccl.so is built by __graft_entry__.build() and carries the eleven symbols exchange_api.hip.h looks up."""
     import __graft_entry__ as ge
     ge.build()
     assert os.path.exists(FAKE) and os.path.exists(EXE)
@@ -193,6 +194,53 @@ def test_exchange_ranks_overflow_on_one_rank_reaches_every_rank(tmp_path):
         for k in range(steps):
             assert per_rank[q][k]["rows"][1]["totals"][2] & 2 and per_rank[q][k]["rows"][0]["totals"][2] == 0
     assert per_rank[1][0]["own"]["flags"] & 2 and 0 < per_rank[1][0]["own"]["nk"] <= 8 * F * N_OCT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline,synchronous", [(2, 0), (1, 1)])
+def test_exchange_rank_dies_and_the_others_abort_within_the_deadline(tmp_path, pipeline, synchronous):
+    """Three ranks; rank 1 kills itself (SIGKILL) after submitting step 3, before its gather.  A collective completes only if every
+    rank takes part, so the other two would wait for ever inside a host wait of the exchange; with SIFTMI_EXCHANGE_TIMEOUT_S = 3
+    every such wait is a bounded poll that aborts the communicator on expiry: both survivors return SIFTMI_E_HIP naming their rank
+    and step 3, in well under 10 s after the kill, and exit by themselves (nobody is restarted)."""
+    import time
+    import __graft_entry__ as ge
+    ge.build()
+    world, steps, K, R = 3, 8, 3, 1
+    d = tmp_path / ("die_p%d_s%d" % (pipeline, synchronous))
+    d.mkdir()
+    env = dict(os.environ, SIFTMI_RCCL_LIB=FAKE, FAKE_RCCL_TIMEOUT_S="60", SIFTMI_EXCHANGE_TIMEOUT_S="3")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(world):
+        small, large = rank_frames(r)
+        np.concatenate([small, large]).tofile(str(d / ("frames%d.bin" % r)))
+        cmd = [EXE, str(W), str(H), str(N_OCT), str(F), str(r), str(world), str(steps), "die:%d:%d" % (K, R), str(pipeline), str(synchronous),
+               str(d / "unique_id"), str(d / ("frames%d.bin" % r)), str(d / ("out%d.bin" % r))]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env))
+    procs[R].wait(timeout=120)                                    # the moment of the kill (start-up and the first steps are not counted)
+    t_dead = time.monotonic()
+    assert procs[R].returncode == -9, procs[R].returncode
+    ends = {}
+    try:
+        for r in range(world):
+            if r != R:
+                procs[r].wait(timeout=30)
+                ends[r] = time.monotonic() - t_dead
+    finally:
+        for q in procs:                                           # exactly the processes started here
+            if q.poll() is None:
+                q.kill()
+    for r in range(world):
+        o, e = procs[r].communicate()
+        e = e.decode("utf-8", "replace")
+        if r == R:
+            assert "dying at step %d" % K in e
+            continue
+        assert procs[r].returncode == 3, (r, procs[r].returncode, e[-1500:])
+        assert ends[r] < 10.0, ends
+        assert "rank %d of %d" % (r, world) in e and "timed out" in e and ("step %d" % K) in e and "communicator aborted" in e, e[-1500:]
+        assert "rank %d ok" % r not in o.decode()
 
 
 @pytest.mark.gpu

@@ -261,6 +261,29 @@ def test_host_batch_call_sub_batches_graphs_and_incremental_copy_back(sm):
     eng.close(); e1.close()
 
 
+@pytest.mark.parametrize("n_frames,lockstep", [(64, 8), (128, 8), (11, 4)])
+def test_host_batch_call_replays_one_graph_per_sub_batch(sm, n_frames, lockstep):
+    """the host-fed call's sub-batch graphs were never captured in the shape bench.py measures -- the signature
+    held the staging slot, which toggled across calls, and the 16-entry candidate list was cycled through before any signature came
+    back (64 frames at max_batch 8: 9 sub-batches x 2 slots).  Now a call starts on slot 0 and the candidate list holds a call's
+    sub-batches: call 1 issues direct launches, call 2 captures one graph per sub-batch, later calls only replay -- same records."""
+    frames = np.stack([blob_frame(320, 240, i % 16, n_blobs=40) for i in range(n_frames)])
+    pin = sm.pinned_empty(frames.shape, np.uint8)
+    pin[...] = frames
+    eng = sm.Engine(320, 240, n_octaves=3, max_batch=lockstep)
+    first = lockstep // 4 if n_frames > lockstep and lockstep >= 4 else lockstep
+    n_sub = 1 + -(-(n_frames - first) // lockstep) if first < lockstep else -(-n_frames // lockstep)
+    want = None
+    for call in range(4):
+        got = eng.detect_describe_batch(pin)
+        st = eng.graph_stats()
+        assert st["direct"] == n_sub and st["captures"] == (n_sub if call >= 1 else 0) and st["replays"] == n_sub * call, (call, st, n_sub)
+        assert want is None or all(g.tobytes() == w_.tobytes() for g, w_ in zip(got, want)), call
+        want = got
+    sm.pinned_release(pin)
+    eng.close()
+
+
 @pytest.mark.parametrize("mode", ["default", "march_skip"])
 def test_formats_agree(sm, mode):
     """GRAY8, GRAYF32 and BGRA8 inputs of the same picture, through the tile seed kernel (default) and through the marching
@@ -392,10 +415,77 @@ def test_device_resident_batch_graph_replay_matches_host_api(sm):
     assert np.array_equal(r2["keypoints"], want[0]) and np.array_equal(r2["descriptors"], want[2])
 
 
+def _translated_quadrant_check(sm, k4, kc4, d4, dc4, k8, kc8, d8, dc8, n_oct, tile):
+    """Every keypoint / descriptor of the 2 x 2 mosaic run (k8 ...) that lies farther than the halo reach from a seam must be the
+    single-tile run's record (k4 ...) translated by its quadrant's offset, and vice versa.  Bit for bit in every field that is
+    translation invariant (octave, scale, subScale, sigma, value, theta, the 128 features); scaledCoordinate minus the offset;
+    normalizedCoordinate recomputed ((float)x / (float)w); absoluteCoordinate = ((float)x + alpha) * delta rounds the SUM at the
+    magnitude of x, and alpha itself is not in the record: the tile run's own rounded sum pins alpha to half an ulp there, so the
+    mosaic run's value (rounded at the magnitude of x + offset) is determined to within one ulp -- asserted, exact in quadrant (0, 0)."""
+    rep = {"kp_compared": 0, "desc_compared": 0, "abs_ulp_off": 0, "trunc_knife_edge": 0}
+    pk4 = np.concatenate([[0], np.cumsum(kc4)]); pk8 = np.concatenate([[0], np.cumsum(kc8)])
+    pd4 = np.concatenate([[0], np.cumsum(dc4)]); pd8 = np.concatenate([[0], np.cumsum(dc8)])
+    for o in range(n_oct):
+        delta = np.float32(0.5 * 2 ** o)
+        w4 = int(tile / float(delta)); w8 = 2 * w4
+        M = 128                                              # octave pixels: seed + cumulative blur (63) + refinement moves (5) + descriptor window (41), rounded up
+        a, b = k4[pk4[o]:pk4[o + 1]], k8[pk8[o]:pk8[o + 1]]
+        da, db = d4[pd4[o]:pd4[o + 1]], d8[pd8[o]:pd8[o + 1]]
+        assert (a["octave"] == o).all() and (b["octave"] == o).all()
+        for qy in range(2):
+            for qx in range(2):
+                ox, oy = qx * w4, qy * w4
+                # safe = farther than M from the seam lines x = w4, y = w4 of the mosaic (true borders are the tile's own borders)
+                def safe(x, y, ox=ox, oy=oy, qx=qx, qy=qy):
+                    lx, ly = x - ox, y - oy
+                    inq = (lx >= 0) & (lx < w4) & (ly >= 0) & (ly < w4)
+                    okx = (lx < w4 - M) if qx == 0 else (lx >= M)
+                    oky = (ly < w4 - M) if qy == 0 else (ly >= M)
+                    return inq & okx & oky
+                sa = safe(a["x"] + ox, a["y"] + oy)
+                sb = safe(b["x"], b["y"])
+                ia, ib = np.nonzero(sa)[0], np.nonzero(sb)[0]
+                key_a = (a["scale"][ia].astype(np.int64) * w8 + a["y"][ia] + oy) * w8 + a["x"][ia] + ox
+                key_b = (b["scale"][ib].astype(np.int64) * w8 + b["y"][ib]) * w8 + b["x"][ib]
+                assert np.array_equal(key_a, np.sort(key_a)) and np.array_equal(key_b, np.sort(key_b))     # (scale, y, x) order on both sides
+                assert np.array_equal(key_a, key_b), (o, qy, qx, len(key_a), len(key_b))                     # the same keypoint set, duplicates included
+                A, B = a[ia], b[ib]
+                for f in ("scale", "sub_scale", "sigma", "value"):
+                    assert A[f].tobytes() == B[f].tobytes(), (o, qy, qx, f)
+                assert (B["norm_x"] == B["x"].astype(np.float32) / np.float32(w8)).all() and (B["norm_y"] == B["y"].astype(np.float32) / np.float32(w8)).all()
+                for f, off, c in (("abs_x", ox, "x"), ("abs_y", oy, "y")):
+                    s4 = A[f].astype(np.float64) / float(delta)                                             # fl(x + alpha), exact (delta is a power of two)
+                    want = ((B[c].astype(np.float64) + (s4 - A[c])).astype(np.float32) * delta).astype(np.float32)
+                    ulp = np.abs(want.view(np.int32).astype(np.int64) - B[f].view(np.int32).astype(np.int64))
+                    assert ulp.max(initial=0) <= (1 if off else 0), (o, qy, qx, f, int(ulp.max()))
+                    rep["abs_ulp_off"] += int((ulp != 0).sum())
+                rep["kp_compared"] += len(ia)
+                # descriptors of those keypoints.  Orientation and descriptor start from Int32(absoluteCoordinate) (SIFTOctave.swift:333-334,
+                # 417-418): where the one-ulp freedom above moves a coordinate across an integer the two runs describe different windows --
+                # those keypoints are set aside (counted); for all others every descriptor must be bit-identical
+                tr = lambda v: np.trunc(v).astype(np.int64)
+                same = (tr(B["abs_x"]) - tr(A["abs_x"]) == int(ox * float(delta))) & (tr(B["abs_y"]) - tr(A["abs_y"]) == int(oy * float(delta)))
+                rep["trunc_knife_edge"] += int((~same).sum())
+                rank_a = np.full(len(a), -1, np.int64); rank_a[ia] = np.arange(len(ia))
+                rank_b = np.full(len(b), -1, np.int64); rank_b[ib] = np.arange(len(ib))
+                ra, rb = rank_a[da["keypoint"]], rank_b[db["keypoint"]]
+                ka = ra[(ra >= 0)]; kb = rb[(rb >= 0)]
+                ma = (ra >= 0); mb = (rb >= 0)
+                ma[ma] &= same[ka]; mb[mb] &= same[kb]
+                DA, DB = da[ma], db[mb]
+                assert np.array_equal(rank_a[DA["keypoint"]], rank_b[DB["keypoint"]]), (o, qy, qx)              # same keypoints, same number of orientations each
+                assert DA["theta"].tobytes() == DB["theta"].tobytes() and DA["features"].tobytes() == DB["features"].tobytes(), (o, qy, qx)
+                rep["desc_compared"] += len(DA)
+    return rep
+
+
 def test_large_single_tile_4096_6_octaves(sm):
     """BASELINE configs[4] shape (one large aerial tile, 6 octaves) at 4096x4096: pyramid bit-exact on a
-    deep layer of every octave, raw extrema counts equal, keypoint sets agree; plus an 8192x8192 GPU-only
-    run (36 GB of stacks) checked through size-independent properties."""
+    deep layer of every octave, raw extrema counts equal, keypoint sets agree; then configs[4] AT ITS STATED SIZE: an 8192x8192
+    tile (36 GB of stacks, octave 0 = 16384^2 x 6 layers = 6.4 GB: byte offsets past 2^32 inside one octave) built as the 2 x 2
+    mosaic of the oracle-checked 4096 tile.  Every octave's decimation grid aligns with the seams (4096 / 32 = 128) and every stage
+    is position independent, so away from the seams the 8192 run must reproduce the 4096 run's Gaussian layers, keypoints and
+    descriptors translated by the quadrant offset, bit for bit (_translated_quadrant_check)."""
     img = blob_frame(4096, 4096, 11, n_blobs=20000, gray=True)
     eng = sm.Engine(4096, 4096, n_octaves=6)
     k, kc, d, dc = eng.detect_describe_batch(img[None])
@@ -417,14 +507,33 @@ def test_large_single_tile_4096_6_octaves(sm):
     assert int(eng.stats()["raw_extrema"][0, 0]) < int(full.stats()["raw_extrema"][0, 0])        # rows really were skipped
     assert np.array_equal(kc, kcf) and np.array_equal(dc, dcf) and k.tobytes() == kf.tobytes() and d.tobytes() == df.tobytes()
     full.close()
-    del eng, orc, ref
-    big = np.tile(img, (2, 2))                       # 8192 x 8192: the 4096 tile mirrored into a 2x2 mosaic
+    small_layers = {(o, s): eng.gaussian(o, s) for (o, s) in ((0, 5), (0, 1), (2, 5), (5, 3))}
+    del orc, ref
+    eng.close()
+    big = np.tile(img, (2, 2))                       # 8192 x 8192: the 4096 tile as a 2 x 2 mosaic
     e8 = sm.Engine(8192, 8192, n_octaves=6)
     k8, kc8, d8, dc8 = e8.detect_describe_batch(big[None])
     k8b, kc8b, d8b, dc8b = e8.detect_describe_batch(big[None])
-    assert np.array_equal(k8, k8b) and np.array_equal(d8, d8b)          # deterministic
-    assert 3.5 * kc[0].sum() < kc8[0].sum() < 4.5 * kc[0].sum()         # ~4x the content
+    assert k8.tobytes() == k8b.tobytes() and d8.tobytes() == d8b.tobytes()          # deterministic
     assert (np.diff(k8["octave"]) >= 0).all()
+    # Gaussian layers: octave 0 layer 5 lies wholly past byte 2^32 of the frame's stack (5 x 16384^2 x 4 B = 5.4 GB)
+    assert 5 * 16384 * 16384 * 4 > 2 ** 32
+    for (o, s), small in small_layers.items():
+        layer = e8.gaussian(o, s)
+        w4 = small.shape[0]
+        assert layer.shape == (2 * w4, 2 * w4)
+        M = 64                                       # > seed (7) + layers 1-5 (43) in octave 0, 20 + 43 in deeper octaves
+        for qy in range(2):
+            for qx in range(2):
+                ys = slice(0, w4 - M) if qy == 0 else slice(M, w4)
+                xs = slice(0, w4 - M) if qx == 0 else slice(M, w4)
+                q = layer[qy * w4:(qy + 1) * w4, qx * w4:(qx + 1) * w4]
+                assert np.array_equal(q[ys, xs], small[ys, xs]), (o, s, qy, qx)
+        del layer
+    rep = _translated_quadrant_check(sm, k, kc[0], d, dc[0], k8, kc8[0], d8, dc8[0], 6, 4096)
+    assert rep["kp_compared"] > 3.2 * len(k) and rep["desc_compared"] > 3.0 * len(d), (rep, len(k), len(d))     # most of the four quadrants
+    assert rep["trunc_knife_edge"] <= 0.005 * rep["kp_compared"], rep
+    e8.close()
 
 
 def _natural_1080p(butterfly_bgra):
@@ -899,6 +1008,86 @@ def test_frame_stream_two_steps_in_flight_equal_one_at_a_time(sm):
             check(fs.results_host(previous=True), (step - 1) % 3, step - 1)     # read step k-1 while step k runs
     check(fs.results_host(), (n - 1) % 3, n - 1)
     fs.close()
+    eng.close()
+
+
+def test_stream_density_hint_flip_is_byte_identical(sm, butterfly_bgra):
+    """The frame stream picks one of two launch sequences per step from the descriptor totals of an EARLIER step (which one it sees is
+    a matter of timing): dense content runs one chain without the extrema scan's activity flags, sparse content the forked graph with
+    them (csrc/stream_api.hip.h submit_step; SIFT/SIFT.swift:147-238 is one function -- it must give the same answer whatever graph
+    ran).  1080p frames, two steps in flight, content alternating sparse / dense / sparse so that the hint flips in both directions,
+    then every hint value forced on every content: each step's packed records and counts are byte-equal to what a lock-step-1 engine
+    returns per frame, launch_flags say which sequence ran, and raw_extrema_exact tells the truth for it (exact counts = a full scan's
+    when set, a subset when not)."""
+    from siftmetal_amd import _capi, stream as smstream
+    W, H, F = 1920, 1080, 4
+    dense0 = _natural_1080p(butterfly_bgra)
+    sparse = np.stack([blob_frame(W, H, i) for i in range(F)])
+    dense = np.stack([np.roll(dense0, 16 * i, axis=1) for i in range(F)])
+    one = sm.Engine(W, H, n_octaves=4, max_batch=1, count_raw_extrema=1)
+
+    def per_frame(frames):
+        ks, ds, kcs, dcs, raws = [], [], [], [], []
+        for f in frames:
+            k, kc, d, dc = one.detect_describe_batch(f[None])
+            ks.append(k); ds.append(d); kcs.append(kc[0]); dcs.append(dc[0])
+            st = one.stats()
+            assert st["raw_extrema_exact"]
+            raws.append(st["raw_extrema"][0].copy())
+        return np.concatenate(ks).tobytes(), np.stack(kcs), np.concatenate(ds).tobytes(), np.stack(dcs), np.stack(raws)
+
+    want = {"S": per_frame(sparse), "D": per_frame(dense)}
+    one.close()
+    nd_S, nd_D = int(want["S"][3].sum()), int(want["D"][3].sum())
+    assert nd_D / (F * W * H) > 4.8e-3 * 1.3 and nd_S / (F * W * H) < 4.8e-3 / 1.3, (nd_S, nd_D)      # either side of the hint's threshold
+    eng = sm.Engine(W, H, n_octaves=4, max_batch=F)
+    fs = smstream.FrameStream(eng, F, pipeline=2)
+    dev = {"S": smstream.DeviceFrames(sparse), "D": smstream.DeviceFrames(dense)}
+    seen = []                                                                      # (content, launch_flags) per step
+
+    def check(r, content, step):
+        wk, wkc, wd, wdc, wraw = want[content]
+        assert r["overflow_flags"] == 0 and r["step"] == step
+        assert np.array_equal(r["counts"][0], wkc) and np.array_equal(r["counts"][1], wdc), (step, content, r["launch_flags"])
+        assert r["keypoints"].tobytes() == wk and r["descriptors"].tobytes() == wd, (step, content, r["launch_flags"])
+        fl = r["launch_flags"]
+        st = fs.engines[step % 2].stats()                                          # that context's last call is this step (step + 2 not yet submitted)
+        hinted = bool(fl & _capi.STEP_DENSE_HINT)
+        assert bool(fl & _capi.STEP_RAW_EXACT) == st["raw_extrema_exact"] == hinted, (step, fl, st["raw_extrema_exact"])
+        assert bool(fl & _capi.STEP_FORKED) == (bool(fl & _capi.STEP_GRAPH_REPLAY) and not hinted), (step, fl)
+        if hinted:
+            assert np.array_equal(st["raw_extrema"], wraw), (step, content)       # no flags, full scan: every strict extremum counted
+        else:                                                                      # flagged-row scan: a subset is counted; on the blob frames rows really are skipped
+            assert (st["raw_extrema"] <= wraw).all() and (content == "D" or (st["raw_extrema"][:, 0] < wraw[:, 0]).any()), (step, content)
+        seen.append((content, fl))
+
+    def drive(pattern, first_step):
+        for i, content in enumerate(pattern):
+            fs.run(dev[content])
+            if i >= 1:
+                check(fs.results_host(previous=True), pattern[i - 1], first_step + i - 1)      # step k-1 while step k runs
+        check(fs.results_host(), pattern[-1], first_step + len(pattern) - 1)
+        return first_step + len(pattern)
+
+    pattern = "SSSS" + "DDDDDD" + "SSSSSS" + "DDDD" + "SS"
+    nxt = drive(pattern, 0)
+    hints = [bool(fl & _capi.STEP_DENSE_HINT) for _, fl in seen]
+    flips = [(a, b) for a, b in zip(hints, hints[1:]) if a != b]
+    assert (False, True) in flips and (True, False) in flips, hints               # the hint went up AND came down again
+    assert not hints[0] and any(h for (c, _), h in zip(seen, hints) if c == "D") and any(not h for (c, _), h in zip(seen, hints) if c == "S")
+    # the hint lags the content: some step ran dense content on the sparse form or sparse content on the dense form -- same bytes (checked above)
+    assert any(h != (c == "D") for (c, _), h in zip(seen, hints)), list(zip(pattern, hints))
+    assert any(fl & _capi.STEP_GRAPH_REPLAY for _, fl in seen)
+    # every hint value forced on every content
+    for mode, want_hint in ((2, True), (1, False), (2, True), (0, None)):
+        fs.set_density_mode(mode)
+        n0 = len(seen)
+        nxt = drive("SDSDDS", nxt)
+        if want_hint is not None:
+            assert all(bool(fl & _capi.STEP_DENSE_HINT) == want_hint for _, fl in seen[n0:]), (mode, seen[n0:])
+    fs.close()
+    for v in dev.values():
+        v.close()
     eng.close()
 
 
