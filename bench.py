@@ -7,14 +7,19 @@
 One step = one pass of the hot path (gray -> 2x bilinear -> Gaussian pyramid -> DoG extrema ->
 refinement -> orientation -> 128-D descriptors, packed results) over a batch of synthetic
 1920x1080 frames per GPU (BASELINE.json configs[2]/[3]: 64 frames per GPU, 4 octaves x 3 scales per
-octave), frames already resident in HBM, results left in HBM; with N > 1 every rank processes its own
-64 frames (frame-per-GPU sharding, weak scaling) and the step ends with the RCCL all-gather of the
-descriptor buffers.  Rank 0 prints ONE JSON line.
+octave).  `value` is the metric as SURVEY.md 8d words it: the frames start in page-locked HOST memory and cross PCIe
+(H2D) inside the timed region, and every step's packed keypoints + descriptors are copied back to page-locked host memory
+(D2H) inside it; with N > 1 every rank processes its own 64 frames (frame-per-GPU sharding, weak scaling) and every step's
+results are also all-gathered over RCCL.  The same step with the frames already resident in HBM and the results left there
+is reported beside it (`resident_Mpixels_per_s`), with `h2d_floor_ms` = the step's upload at the synchronous H2D rate measured
+in the run, so that the line itself says when a step is PCIe-bound.  Rank 0 prints ONE JSON line.
 
-The timed loop calls only the C ABI's frame stream (siftmi_stream_submit_device / siftmi_exchange_gather through the ctypes
-binding siftmetal_amd/stream.py): frames live in HBM allocated with siftmi_device_alloc, two steps in flight, host-fed
-staging and the RCCL exchange are all inside libsiftmi.so.  torch is used for the contract's synchronize() and, with
-N > 1, as the control plane only (gloo: hands rank 0's ncclUniqueId to the other ranks, barrier, max over ranks).
+The timed loop calls only the C ABI's frame stream (siftmi_stream_submit_host / siftmi_stream_result_host /
+siftmi_exchange_gather through the ctypes binding siftmetal_amd/stream.py): uploads on a copy stream into rotating staging
+buffers, two steps in flight, copy-back on a third stream and the RCCL exchange are all inside libsiftmi.so.  torch is used for
+the contract's synchronize() and, with N > 1, as the control plane only (gloo: hands rank 0's ncclUniqueId to the other ranks,
+barrier, max over ranks).  A rank that dies or hangs ends the job: the exchange's waits are bounded (SIFTMI_EXCHANGE_TIMEOUT_S),
+the error propagates as an exception, the process exits non-zero; nothing is restarted or re-executed.
 
 `--gpus N` with N > 1 and no torchrun environment: this process spawns the N ranks itself (before any
 GPU call) and relays rank 0's line; it exits non-zero if fewer than N devices are visible or the
@@ -27,9 +32,9 @@ Extra objects in the line:
   cpu_baseline the CPU oracle (a port of the reference's algorithm; kind "port") timed on the host
                cores on a bounded sample of the same frames: all cores, and one thread.
   config.single_frame / config.host_io / config.dense
-               BASELINE configs[1] (one frame per call), the same 64-frame step fed from pinned host
-               memory with the packed results copied back (PCIe-inclusive; never `value`), and the
-               step on 64 dense natural-texture frames (mirror-tiled butterfly, ~7x the keypoints).
+               BASELINE configs[1] (one frame per call), the same 64-frame step through the SYNCHRONOUS
+               host-buffer call (siftmi_detect_describe_batch), and the step on 64 dense natural-texture
+               frames (mirror-tiled butterfly, ~7x the keypoints), resident and host-fed.
 """
 import argparse
 import json
@@ -246,7 +251,8 @@ def main():
         # control plane only (unique id, barrier, max over ranks): the data path's RCCL communicator lives in libsiftmi.so
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node: the loopback interface (the box's hostname may not resolve)
-        dist.init_process_group("gloo")
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=20))   # (rank 0's extra measurements run while the others wait at the last barrier)
         if dist.get_world_size() != world:
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
 
@@ -262,7 +268,9 @@ def main():
     frames_np = make_frames(F, args.distinct)
     # every rank gets different frames (rotate) so the gathered descriptors are not copies
     frames_np = np.roll(frames_np, rank, axis=0)
-    d_frames = smstream.DeviceFrames(frames_np, local_rank)      # HBM through siftmi_device_alloc / siftmi_memcpy
+    hpin = sm.pinned_empty(frames_np.shape, np.uint8)            # the frames as a capture loop delivers them: page-locked host memory
+    hpin[...] = frames_np
+    d_frames = smstream.DeviceFrames(frames_np, local_rank)      # HBM through siftmi_device_alloc / siftmi_memcpy (the resident figure, roofline pass)
     tune = {"blur_march_min_blocks": args.march_min_blocks} if args.march_min_blocks > 0 else {}
     if args.serial_graph:
         tune["graph_fork"] = -1
@@ -276,34 +284,46 @@ def main():
         if world > 1:
             dist.broadcast_object_list(box, src=0)
         uid = box[0]
-    # the timed stream: consecutive steps alternate between two contexts, so that step k+1's HBM-bound dense stages run under
-    # step k's VALU-bound keypoint stages; `plain` (one context, one step at a time) is what the per-kernel measurements use
+    # the timed stream: host-fed (upload of step k+1 under the kernels of step k), consecutive steps alternate between two contexts
+    # (step k+1's HBM-bound dense stages run under step k's VALU-bound keypoint stages), every step's packed results copied back to
+    # page-locked host memory and read `back` steps late; `plain` (one context, one step at a time, resident frames) is what the
+    # per-kernel measurements use
     runner = smstream.FrameStream(eng, F, device=dev, world_size=world, overlap_gather=use_dist, pipeline=args.pipeline,
                                   result_sets=2 * args.pipeline, rank=rank, unique_id=uid)
-    plain = smstream.FrameStream(eng, F, device=dev) if args.pipeline > 1 else runner
+    plain = smstream.FrameStream(eng, F, device=dev)
+    back = args.pipeline
+    rccl_ranks = runner.exchange.ranks()[0] if use_dist else 0       # what the communicator itself reports, not the environment
+    if use_dist and rccl_ranks != world:
+        raise SystemExit("bench.py: the communicator has %d ranks, WORLD_SIZE is %d" % (rccl_ranks, world))
 
     def dev_sync():
         torch.cuda.synchronize()
         _capi.check(_capi.load().siftmi_device_synchronize(local_rank))
 
     def barrier():
+        if use_dist:
+            runner.exchange.wait()   # bounded: a collective that cannot complete (a rank is gone) raises here instead of hanging the device sync
         if world > 1:
             dist.barrier()
         dev_sync()
 
     def step():
-        runner.run(d_frames)
+        runner.run_host(hpin)
         if use_dist:
-            runner.all_gather()      # on a side stream, from one of two alternating result sets: overlaps the next step's kernels
+            runner.all_gather()      # on a side stream, from one of the rotating result sets: overlaps the next step's kernels
+        if runner.step_no >= back:   # views of the stream's page-locked buffers: nothing is allocated in the timed loop
+            return runner.results_host(back=back, copy=False)
+        return None
 
     # reference counts from one synchronised step; every later step (graph replays included) must reproduce them
     step()
     barrier()
     first = runner.results_host()
-    if use_dist or args.pipeline > 1:   # every (context, result set) launch sequence captured (second sighting each) before anything is timed
-        for _ in range(2 * runner.n_sets):
-            step()
-        barrier()
+    # warm-up: every (staging buffer, result set, context) pairing seen twice (captured, then replayed), every result set's
+    # page-locked host buffers allocated
+    for _ in range(2 * runner.n_sets + 2):
+        step()
+    barrier()
     g0 = runner.exchange.stats() if use_dist else None
     dt = timed_steps(step, barrier, args.steps, args.warmup)
     rank_ms = [dt / args.steps * 1e3]
@@ -317,6 +337,7 @@ def main():
     value = world * F * W * H * args.steps / dt / 1e6
     gather_ms = gather_bytes = None
     regathered = overflowed = 0
+    checksum = None
     if use_dist:
         regathered, overflowed = runner.exchange.finish()
         if overflowed:
@@ -324,6 +345,22 @@ def main():
         g1 = runner.exchange.stats()
         gather_ms = (g1["ms"] - g0["ms"]) / max(g1["gathers"] - g0["gathers"], 1)
         gather_bytes = g1["bytes_last"]
+        # what the collective delivered: a checksum of every rank's row of the last gathered step, equal on every rank or the line is not printed
+        import zlib
+        gh = runner.exchange.result_host(0)
+        crc = 0
+        for r in range(world):
+            crc = zlib.crc32(gh["descriptors"][r].tobytes(), zlib.crc32(gh["keypoints"][r].tobytes(), crc))
+        crcs = [crc]
+        if world > 1:
+            tc = torch.tensor([crc], dtype=torch.int64)
+            got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(got, tc)
+            crcs = [int(x.item()) for x in got]
+        if len(set(crcs)) != 1 or not gh["complete"]:
+            raise SystemExit("bench: the ranks hold different gathered results (crc32 by rank %s, complete %s)" % (crcs, gh["complete"]))
+        checksum = {"crc32_of_gathered_keypoints_and_descriptors": "%08x" % crc, "equal_on_all_ranks": True, "ranks_compared": len(crcs),
+                    "records_gathered": [int(sum(len(x) for x in gh["keypoints"])), int(sum(len(x) for x in gh["descriptors"]))]}
 
     res = runner.results_host()
     if (res["n_keypoints"], res["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]) or \
@@ -331,39 +368,68 @@ def main():
         raise SystemExit("bench: results of the last timed step differ from the first step (%d/%d vs %d/%d keypoints/descriptors): "
                          "the timed region did not compute the workload" %
                          (res["n_keypoints"], res["n_descriptors"], first["n_keypoints"], first["n_descriptors"]))
-    log("rank0 per-step: %d keypoints, %d descriptors over %d frames; %.3f ms/step, %.3f ms/frame" %
+    d2h_bytes = int(res["keypoints"].nbytes + res["descriptors"].nbytes + res["counts"].nbytes)
+    log("rank0 per-step: %d keypoints, %d descriptors over %d frames; %.3f ms/step, %.3f ms/frame (host-fed, results to host)" %
         (res["n_keypoints"], res["n_descriptors"], F, ms_per_step, ms_per_step / F))
 
     out = {"metric": "Mpixels/sec detect+describe (1920x1080, 4 octaves)", "value": round(value, 2), "unit": "Mpixels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%d x 1920x1080 BGRA8 frames per GPU per step (BASELINE configs[2]/[3]; %d distinct synthetic frames), %d octaves x %d scales/octave, "
-                                  "detect+describe, frames and results resident in HBM%s.  `value` EXCLUDES PCIe; the metric as SURVEY.md 8d words it (H2D of the "
-                                  "frames and D2H of keypoints + descriptors included) is host_io_stream_Mpixels_per_s in this line" %
-                                  (F, min(F, args.distinct), N_OCT, NSPO, ", RCCL all-gather of descriptors" if world > 1 else ""),
+                                  "detect+describe as SURVEY.md 8d words the metric: frames uploaded from page-locked host memory (H2D) and every step's packed "
+                                  "keypoints + descriptors copied back to page-locked host memory (D2H) inside the timed region%s" %
+                                  (F, min(F, args.distinct), N_OCT, NSPO, ", plus the RCCL all-gather of every rank's results" if world > 1 else ""),
                       "frames_per_gpu": F, "lockstep_batch": eng.max_batch, "parallelism": "frame-per-GPU x%d" % world,
                       "steps_in_flight": args.pipeline,
-                      "pipelining": ("consecutive steps alternate between two contexts (two pyramids, two streams): a step's HBM-bound dense "
-                                     "stages run under the previous step's VALU-bound keypoint stages; every step is computed in full, the "
-                                     "timed region ends with a device synchronisation") if args.pipeline > 1 else None,
-                      "rccl_ranks": world if use_dist else 0,
+                      "pipelining": ("siftmi_stream_submit_host / siftmi_stream_result_host (C ABI): the upload of step k+1 runs under the kernels of step k (copy "
+                                     "stream, rotating staging buffers); consecutive steps alternate between two contexts (two pyramids, two streams); every "
+                                     "step's results are copied to page-locked host memory (copy started at submit time) and read %d steps late; every step is "
+                                     "computed in full, the timed region ends with a device synchronisation" % back),
+                      "h2d_bytes_per_step": int(hpin.nbytes), "d2h_bytes_per_step": d2h_bytes,
+                      "rccl_ranks": rccl_ranks,
+                      "rccl_ranks_source": "ncclCommCount of the exchange's communicator (checked against WORLD_SIZE)" if use_dist else None,
                       "ranks_share_one_gpu": bool(args.share_gpu),
                       "all_gather_transport": transport,
                       "ms_per_step_by_rank": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
                       "all_gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4),
                       "all_gather_bytes_received_per_rank_per_step": gather_bytes,
                       "all_gather_steps_regathered": regathered, "all_gather_steps_overflowed": overflowed,
+                      "all_gather_checksum": checksum,
                       "all_gather": ("siftmi_exchange_gather (librccl inside libsiftmi.so) on a side stream, rotating result sets: step k's exchange "
-                                     "runs under step k+1's kernels; payload sizes from step k-1's totals") if use_dist else None,
+                                     "runs under step k+1's kernels; payload sizes from step k-1's totals; every host wait bounded "
+                                     "(SIFTMI_EXCHANGE_TIMEOUT_S), expiry aborts the communicator and ends the job") if use_dist else None,
                       "host_binding": "ctypes -> siftmi_stream_* / siftmi_exchange_* (C ABI); no torch tensors or torch.distributed in the data path",
                       "keypoints_per_step_rank0": res["n_keypoints"], "descriptors_per_step_rank0": res["n_descriptors"]}}
 
-    if rank == 0 and args.pipeline > 1:
-        # the same K steps one at a time on one context: what the pipelining buys
+    if rank == 0:
+        # the upload alone at the synchronous H2D rate of this box, measured now: when ms_per_step is close to it the step is PCIe-bound
+        t1 = time.perf_counter()
+        for _ in range(3):
+            _capi.check(_capi.load().siftmi_memcpy(d_frames.ptr, hpin.ctypes.data, hpin.nbytes, 0))
+        h2d_gbs = 3 * hpin.nbytes / (time.perf_counter() - t1) / 1e9
+        out["h2d_floor_ms"] = round(hpin.nbytes / h2d_gbs / 1e6, 4)
+        out["config"]["synchronous_h2d_GBps"] = round(h2d_gbs, 1)
+        out["config"]["h2d_floor_how"] = "h2d_bytes_per_step / the rate of three synchronous siftmi_memcpy calls from the same page-locked frames (this box, this run)"
+        # the same K steps with the frames resident in HBM and the results left there (rounds 1-4 quoted this as `value`)
+        rrun = smstream.FrameStream(eng, F, device=dev, pipeline=args.pipeline, result_sets=2 * args.pipeline)
+        for _ in range(2 * rrun.n_sets + 1):
+            rrun.run(d_frames)
+        dev_sync()
+        dtr = timed_steps(lambda: rrun.run(d_frames), dev_sync, args.steps, 2)
+        rres = rrun.results_host()
+        if (rres["n_keypoints"], rres["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]):
+            raise SystemExit("bench: resident-frame results differ from the host-fed ones")
+        out["resident_ms_per_step"] = round(dtr / args.steps * 1e3, 4)
+        out["resident_Mpixels_per_s"] = round(F * W * H * args.steps / dtr / 1e6, 1)
+        out["config"]["resident"] = ("the same step through siftmi_stream_submit_device: frames already in HBM, results left in HBM, %d steps in flight, "
+                                     "this rank alone (no exchange)" % args.pipeline)
+        rrun.close()
+        log("resident frames: %.3f ms/step (%.0f Mpixels/s); synchronous H2D %.1f GB/s -> upload floor %.3f ms/step" %
+            (out["resident_ms_per_step"], out["resident_Mpixels_per_s"], h2d_gbs, out["h2d_floor_ms"]))
+        # the same K resident steps one at a time on one context: what the pipelining buys
         dt1 = timed_steps(lambda: plain.run(d_frames), dev_sync, args.steps, 3)
-        out["config"]["ms_per_step_one_in_flight"] = round(dt1 / args.steps * 1e3, 4)
-        out["ms_per_step_one_in_flight"] = out["config"]["ms_per_step_one_in_flight"]
-        log("one step in flight: %.3f ms/step" % (dt1 / args.steps * 1e3))
+        out["resident_ms_per_step_one_in_flight"] = round(dt1 / args.steps * 1e3, 4)
+        log("resident, one step in flight: %.3f ms/step" % (dt1 / args.steps * 1e3))
     if rank == 0 and not args.no_roofline:
         # second, identical pass with per-launch hipEvents on the launch stream
         eng.enable_timings(True)
@@ -413,6 +479,13 @@ def main():
                 traffic = int(ratio * total_bytes / max(blur_n, 1))
                 traffic_src = ("profiles/%s: PMC bytes / algorithmic bytes = %.3f averaged over the five octave-0 layer launches of the "
                                "pipeline, scaled to the average launch" % (prof[-1], ratio))
+        # the same fraction recomputed from the committed rocprofv3 kernel trace of this command (tools/profile_round.sh, serial graph: every
+        # kernel alone on the GPU, under the profiler's clocks, on whatever box that run got): a number a reader can re-derive from profiles/
+        rp, rp_src = None, None
+        prof_r = sorted(f for f in os.listdir(pdir) if f.startswith("roofline_rocprof_")) if os.path.isdir(pdir) else []
+        if prof_r:
+            rp = json.load(open(os.path.join(pdir, prof_r[-1])))
+            rp_src = "profiles/%s (from %s)" % (prof_r[-1], rp.get("source"))
         # the ceilings, measured on THIS device in THIS run: a plain float4 copy of one octave-0 layer launch's bytes
         # inside the same pyramid memory, and the ring kernel itself with its arithmetic compiled out (same loads, LDS staging,
         # barriers and stores).  Both overwrite the pyramid; every later measurement recomputes it.
@@ -435,6 +508,9 @@ def main():
                            "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "traffic_source": traffic_src,
+                           "frac_rocprof": None if rp is None else rp.get("frac_all_layers"),
+                           "frac_rocprof_octave0": None if rp is None else rp.get("frac_octave0"),
+                           "frac_rocprof_source": rp_src,
                            "peak_measured": round(copy_gbs, 1), "frac_of_measured": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None,
                            "peak_measured_how": "siftmi_time_copy: one-pass float4 streaming copy of %.2f GB (read + written) inside this context's pyramid memory, the faster "
                                                 "of plain and non-temporal loads / stores, mean of 10 launches after a warm-up, hipEvents, this device, this run" % (copy_moved / 1e9),
@@ -483,76 +559,66 @@ def main():
         log("single frame: %.3f ms (%.0f Mpixels/s); two calls in flight: %.3f ms per frame" % (ms1, W * H / ms1 / 1e3, ms2))
         r1.close(); r2.close(); e1.close(); one.close()
         del r1, r2, e1
-        # the metric as SURVEY.md 8d words it: frames cross PCIe from pinned host memory, packed results are copied back
-        pin = sm.pinned_empty(frames_np.shape, np.uint8)
-        pin[...] = frames_np
-        # its own context with 8-frame sub-batches (the first one 2 frames): the H2D copy of sub-batch i+1 runs under the kernels of
-        # sub-batch i, the packed results of finished sub-batches are copied back under the later ones
+        # The SYNCHRONOUS host-buffer entry (siftmi_detect_describe_batch) on the same page-locked frames: its own context with 8-frame
+        # sub-batches (the first one 2 frames); the H2D copy of sub-batch i+1 runs under the kernels of sub-batch i, the packed results of
+        # finished sub-batches are copied back under the later ones.  Warm-up until every sub-batch's launch sequence is replayed from its
+        # captured graph (call 1 direct launches, call 2 captures; siftmi_graph_stats), then timed.
         eio = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=8)
-        eio.detect_describe_batch(pin, copy=False)
+        for _ in range(3):
+            eio.detect_describe_batch(hpin, copy=False)
+        gs0 = eio.graph_stats()
         reps = 3
         t1 = time.perf_counter()
         for _ in range(reps):
-            k, kc, d, dc = eio.detect_describe_batch(pin, copy=False)
+            k, kc, d, dc = eio.detect_describe_batch(hpin, copy=False)
         ms_io = (time.perf_counter() - t1) / reps * 1e3
-        out["config"]["host_io"] = {"workload": "the same %d-frame step through siftmi_detect_describe_batch: BGRA8 frames in pinned host memory "
-                                                "(8-frame sub-batches, captured launch sequences: the H2D copy of sub-batch i+1 runs under the kernels of sub-batch i, results of finished "
+        gs1 = eio.graph_stats()
+        out["config"]["host_io"] = {"workload": "the same %d-frame step through the synchronous call siftmi_detect_describe_batch: BGRA8 frames in pinned host memory "
+                                                "(8-frame sub-batches, one captured launch sequence each: the H2D copy of sub-batch i+1 runs under the kernels of sub-batch i, results of finished "
                                                 "sub-batches are copied back under the later ones); a synchronous call cannot hide its first upload or its last sub-batch: "
                                                 "time >= max(upload + last sub-batch, first upload + all kernels)" % F,
                                     "ms_per_step": round(ms_io, 4), "Mpixels_per_s": round(F * W * H / ms_io / 1e3, 1),
-                                    "h2d_bytes_per_step": int(pin.nbytes), "d2h_bytes_per_step": int(k.nbytes + d.nbytes),
-                                    "keypoints": int(len(k)), "descriptors": int(len(d))}
-        log("host i/o step: %.3f ms (%.0f Mpixels/s)" % (ms_io, F * W * H / ms_io / 1e3))
+                                    "h2d_bytes_per_step": int(hpin.nbytes), "d2h_bytes_per_step": int(k.nbytes + d.nbytes),
+                                    "keypoints": int(len(k)), "descriptors": int(len(d)),
+                                    "launch_sequences_in_the_timed_calls": {"graph_replays": gs1["replays"] - gs0["replays"], "captures": gs1["captures"] - gs0["captures"],
+                                                                            "direct": gs1["direct"] - gs0["direct"]}}
+        log("host i/o, synchronous call: %.3f ms (%.0f Mpixels/s) %s" % (ms_io, F * W * H / ms_io / 1e3, out["config"]["host_io"]["launch_sequences_in_the_timed_calls"]))
         del k, d
         eio.close()
-        sm.pinned_release(pin)
-        # the same metric through the frame stream: uploads on a copy stream into alternating staging buffers, so the PCIe
-        # transfer of step k+1 runs under the kernels of step k, and step k's results are copied back while k+1 runs
-        hpin = sm.pinned_empty(frames_np.shape, np.uint8)
-        hpin[...] = frames_np
-        t1 = time.perf_counter()
-        for _ in range(3):
-            _capi.check(_capi.load().siftmi_memcpy(d_frames.ptr, hpin.ctypes.data, hpin.nbytes, 0))
-        h2d_gbs = 3 * hpin.nbytes / (time.perf_counter() - t1) / 1e9
-        ehs = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), **tune)
-        hs = smstream.FrameStream(ehs, F, device=dev, pipeline=args.pipeline, result_sets=2 * args.pipeline)
-        back = args.pipeline                              # read step i - back after launching step i: the upload of step i+1 is
-        for i in range(2 * hs.n_sets + 2):                # then issued while steps i-1 and i still run.  Warm-up: every (staging
-            hs.run_host(hpin)                             # buffer, result set) pairing seen twice (captured, then replayed) and
-            if i >= back:                                 # every result set's page-locked host buffers allocated
-                hs.results_host(back=back, copy=False)
+        # dense natural texture: the same step on 64 mirror-tiled butterfly frames (not sparse synthetic blobs), resident and host-fed
+        dense_np = make_dense_frames(F)
+        d_dense = smstream.DeviceFrames(dense_np, local_rank)
+        drun = smstream.FrameStream(eng, F, device=dev, pipeline=args.pipeline, result_sets=2 * args.pipeline)
+        drun.run(d_dense)
         dev_sync()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            hs.run_host(hpin)
-            rio = hs.results_host(back=back, copy=False)  # views of the stream's page-locked buffers: nothing is allocated in the timed loop
-        dev_sync()
-        ms_ios = (time.perf_counter() - t1) / args.steps * 1e3
-        if (rio["n_keypoints"], rio["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]):
-            raise SystemExit("bench: host-fed stream results differ from the resident ones")
-        out["config"]["host_io_stream"] = {"workload": "the same step through siftmi_stream_submit_host / siftmi_stream_result_host (C ABI): frames in page-locked host memory, "
-                                                       "upload of step k+1 under the kernels of step k (copy stream, rotating staging buffers), every step's packed "
-                                                       "keypoints + descriptors copied to page-locked host memory (copy started at submit time) and read %d steps late" % back,
-                                           "ms_per_step": round(ms_ios, 4), "Mpixels_per_s": round(F * W * H / ms_ios / 1e3, 1),
-                                           "h2d_bytes_per_step": int(hpin.nbytes), "d2h_bytes_per_step": int(rio["keypoints"].nbytes + rio["descriptors"].nbytes),
-                                           "synchronous_h2d_GBps": round(h2d_gbs, 1)}
-        out["host_io_stream_ms_per_step"] = round(ms_ios, 4)          # SURVEY.md 8d's wording of the metric (PCIe in and out included)
-        out["host_io_stream_Mpixels_per_s"] = round(F * W * H / ms_ios / 1e3, 1)
-        log("host i/o through the frame stream: %.3f ms/step (%.0f Mpixels/s); synchronous H2D %.1f GB/s" % (ms_ios, F * W * H / ms_ios / 1e3, h2d_gbs))
-        del rio
-        hs.close(); ehs.close()
-        sm.pinned_release(hpin)
-        # dense natural texture: the same step on 64 mirror-tiled butterfly frames (not sparse synthetic blobs)
-        d_dense = smstream.DeviceFrames(make_dense_frames(F), local_rank)
-        runner.run(d_dense)
-        dev_sync()
-        dres = runner.results_host()
-        dt_d = timed_steps(lambda: runner.run(d_dense), dev_sync, args.steps, 10)  # warm-up: the density hint settles and both contexts capture this input's (one-chain) launch sequence
+        dres = drun.results_host()
+        dt_d = timed_steps(lambda: drun.run(d_dense), dev_sync, args.steps, 10)  # warm-up: the density hint settles and both contexts capture this input's (one-chain) launch sequence
         ms_d = dt_d / args.steps * 1e3
         out["config"]["dense"] = {"workload": "%d x 1920x1080 mirror-tiled butterfly frames (SURVEY.md 8d dense variant), resident in HBM" % F,
                                   "ms_per_step": round(ms_d, 4), "Mpixels_per_s": round(F * W * H / ms_d / 1e3, 1),
                                   "keypoints_per_step": dres["n_keypoints"], "descriptors_per_step": dres["n_descriptors"]}
         log("dense step: %.3f ms (%.0f Mpixels/s), %d keypoints, %d descriptors" % (ms_d, F * W * H / ms_d / 1e3, dres["n_keypoints"], dres["n_descriptors"]))
+        # ... and as the headline is measured: host-fed, every step's results (27 -> ~190 MB) back to host memory
+        dpin = sm.pinned_empty(dense_np.shape, np.uint8)
+        dpin[...] = dense_np
+
+        def dstep():
+            drun.run_host(dpin)
+            drun.results_host(back=back, copy=False)
+
+        for _ in range(2 * drun.n_sets + 2):
+            dstep()
+        dev_sync()
+        dt_dh = timed_steps(dstep, dev_sync, args.steps, 2)
+        dres_h = drun.results_host()
+        if (dres_h["n_keypoints"], dres_h["n_descriptors"]) != (dres["n_keypoints"], dres["n_descriptors"]):
+            raise SystemExit("bench: host-fed dense results differ from the resident ones")
+        out["config"]["dense"]["host_fed_ms_per_step"] = round(dt_dh / args.steps * 1e3, 4)
+        out["config"]["dense"]["host_fed_Mpixels_per_s"] = round(F * W * H * args.steps / dt_dh / 1e6, 1)
+        out["config"]["dense"]["host_fed_d2h_bytes_per_step"] = int(dres_h["keypoints"].nbytes + dres_h["descriptors"].nbytes)
+        log("dense step, host-fed with results to host: %.3f ms" % (dt_dh / args.steps * 1e3))
+        drun.close()
+        sm.pinned_release(dpin)
         if not args.no_roofline:
             eng.enable_timings(True)
             eng.reset_timings()
@@ -569,10 +635,10 @@ def main():
     # stdout is restored: the contract is ONE JSON line
     if world > 1:
         dist.barrier()                                      # rank 0's extra measurements are done: all ranks leave together (the exchange is collective)
-    if plain is not runner:
-        plain.close()
+    plain.close()
     runner.close()
     eng.close()
+    sm.pinned_release(hpin)
     if world > 1:
         dist.destroy_process_group()
     sys.stdout.flush()

@@ -258,6 +258,7 @@ def test_bench_two_ranks_share_the_gpu_through_the_test_transport():
     d = json.loads(lines[0])
     c = d["config"]
     assert d["n_gpus"] == 2 and c["rccl_ranks"] == 2 and c["ranks_share_one_gpu"] is True
+    assert c["all_gather_checksum"]["equal_on_all_ranks"] and c["all_gather_checksum"]["ranks_compared"] == 2
     assert abs(d["value"] - 2 * 8 * 1920 * 1080 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
     assert c["all_gather_ms_per_step"] > 0 and c["all_gather_steps_overflowed"] == 0
     # world x (counts + keypoint bytes + descriptor bytes + totals) received per rank and step

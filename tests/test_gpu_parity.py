@@ -1447,6 +1447,14 @@ def test_bench_line_contract():
     shapes = r["by_launch_shape"]
     assert len(shapes) == 20 and shapes["o0_l5"]["kernel"].startswith("blur_ring_kernel<13") and shapes["o0_l3"]["decimating"]
     assert "workload" in d["config"] and "model" not in d["config"]
+    # `value` is the metric SURVEY.md 8d defines (H2D of the frames and D2H of the results inside the timed region); the resident figure
+    # and the upload floor stand beside it, and the kernel-trace fraction comes from the committed profile
+    c = d["config"]
+    assert "EXCLUDES" not in c["workload"] and "H2D" in c["workload"] and "D2H" in c["workload"]
+    assert c["h2d_bytes_per_step"] == 64 * 1920 * 1080 * 4 and c["d2h_bytes_per_step"] > 10 ** 7 and c["rccl_ranks"] == 0
+    assert d["resident_Mpixels_per_s"] >= 0.9 * d["value"] and abs(d["resident_Mpixels_per_s"] - 64 * 1920 * 1080 / d["resident_ms_per_step"] / 1e3) < 2
+    assert 0.5 * d["h2d_floor_ms"] < d["ms_per_step"] and abs(d["h2d_floor_ms"] - c["h2d_bytes_per_step"] / c["synchronous_h2d_GBps"] / 1e6) < 0.05
+    assert r["frac_rocprof"] is None or (0.3 < r["frac_rocprof"] < 1 and "profiles/roofline_rocprof_" in r["frac_rocprof_source"])
 
 
 def test_bench_line_with_the_exchange_on_one_rank():
@@ -1464,6 +1472,10 @@ def test_bench_line_with_the_exchange_on_one_rank():
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     c = json.loads(lines[0])["config"]
-    assert c["rccl_ranks"] == 1 and c["all_gather_ms_per_step"] > 0 and c["all_gather_bytes_received_per_rank_per_step"] > 10 ** 6
+    assert c["rccl_ranks"] == 1 and "ncclCommCount" in c["rccl_ranks_source"]
+    ck = c["all_gather_checksum"]
+    assert ck["equal_on_all_ranks"] and len(ck["crc32_of_gathered_keypoints_and_descriptors"]) == 8
+    assert ck["records_gathered"] == [c["keypoints_per_step_rank0"], c["descriptors_per_step_rank0"]]
+    assert c["all_gather_ms_per_step"] > 0 and c["all_gather_bytes_received_per_rank_per_step"] > 10 ** 6
     assert c["all_gather_steps_overflowed"] == 0 and c["all_gather_steps_regathered"] == 0
     assert c["ms_per_step_by_rank"]["min"] == c["ms_per_step_by_rank"]["max"] > 0

@@ -42,6 +42,40 @@ if trace:
         w.writerow(["kernel", "workgroups_x", "grid_y", "grid_z", "calls", "avg_us", "min_us", "max_us", "total_ms"])
         for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k[0], k[1], k[2], k[3], len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2), round(sum(v) / 1e6, 3)])
+    # roofline.frac as the kernel trace gives it (bench.py carries it as roofline.frac_rocprof): one Gaussian-layer launch per (octave, layer)
+    # and step; a launch shape = one kernel instantiation (radius, decimating, flags) x grid.  Seed launches (SEEDF >= 0) and the
+    # memory-only ablation (DBG != 0) are left out; the radius names the layer.
+    OW = [(3840, 2160), (1920, 1080), (960, 540), (480, 270)]
+    FR = 64
+    by_r = collections.defaultdict(list)
+    for (short, gx, gy, gz), v in d.items():
+        m = re.match(r"blur_ring_kernel<(\d+), \d+, \d+, (?:true|false), (?:true|false), (\d+), (-?\d+)", short)
+        m2 = re.match(r"blur2_kernel<(\d+), \d+, \d+, \d+, \d+, (true|false)", short)
+        if m and int(m.group(2)) == 0 and int(m.group(3)) < 0: by_r[int(m.group(1))].append((gx * gy * gz, sum(v) / len(v), len(v), short))
+        elif m2 and m2.group(2) == "false": by_r[int(m2.group(1))].append((gx * gy * gz, sum(v) / len(v), len(v), short))
+    radii = {5: 1, 7: 2, 8: 3, 10: 4, 13: 5}
+    tot_b = tot_ns = o0_b = o0_ns = 0.0
+    rows_r = []
+    ok = True
+    for R, layer in radii.items():
+        # octaves differ 4x in pixels, so the launch shapes of one radius in descending DURATION are octaves 0, 1, 2, ... (not in descending
+        # grid size: the chunk height differs by octave and radius, R = 10 runs octave 1 on 1920 workgroups and octave 2 on 2048)
+        ordered = sorted(by_r.get(R, []), key=lambda t: -t[1])
+        if len(ordered) != len(OW): ok = False
+        for o, t in enumerate(ordered[:len(OW)]):
+            nb = 8.0 * OW[o][0] * OW[o][1] * FR
+            tot_b += nb; tot_ns += t[1]
+            if o == 0: o0_b += nb; o0_ns += t[1]
+            rows_r.append({"octave": o, "layer": layer, "radius": R, "kernel": t[3][:60], "workgroups": t[0], "launches_in_trace": t[2], "avg_us": round(t[1] / 1e3, 2),
+                           "GBps": round(nb / t[1], 1)})
+    if ok and tot_ns > 0:
+        json.dump({"source": "rocprofv3 --kernel-trace of `bench.py --steps 3 --warmup 1 --no-cpu --no-extras --pipeline 1 --serial-graph` (rocprof_kernel_shapes_%s.csv)" % tag,
+                   "algorithmic_bytes_per_step": tot_b, "blur_ms_per_step": round(tot_ns / 1e6, 4), "GBps_all_layers": round(tot_b / tot_ns, 1),
+                   "frac_all_layers": round(tot_b / tot_ns / 8000.0, 4), "GBps_octave0": round(o0_b / o0_ns, 1), "frac_octave0": round(o0_b / o0_ns / 8000.0, 4),
+                   "peak_GBps": 8000.0, "launch_shapes": rows_r}, open(out + "/roofline_rocprof_%s.json" % tag, "w"), indent=1)
+        print("roofline from the kernel trace: all layers %.4f, octave 0 %.4f of 8 TB/s" % (tot_b / tot_ns / 8000.0, o0_b / o0_ns / 8000.0))
+    else:
+        print("roofline from the kernel trace: launch shapes did not map onto 4 octaves x 5 layers:", {R: len(v) for R, v in by_r.items()})
 pst = sorted(glob.glob(out + "/trace_pipelined/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if pst:
     prow = list(csv.DictReader(open(pst[-1])))
