@@ -1020,7 +1020,7 @@ def test_stream_density_hint_flip_is_byte_identical(sm, butterfly_bgra):
     returns per frame, launch_flags say which sequence ran, and raw_extrema_exact tells the truth for it (exact counts = a full scan's
     when set, a subset when not)."""
     from siftmetal_amd import _capi, stream as smstream
-    W, H, F = 1920, 1080, 4
+    W, H, F = 1920, 1080, 5                               # (>= 8 Mpixel per step: the stream samples every step's totals for the hint)
     dense0 = _natural_1080p(butterfly_bgra)
     sparse = np.stack([blob_frame(W, H, i) for i in range(F)])
     dense = np.stack([np.roll(dense0, 16 * i, axis=1) for i in range(F)])
