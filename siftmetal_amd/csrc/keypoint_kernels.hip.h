@@ -1088,6 +1088,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
         // One sample (j = x offset, i = y offset) of the window: SIFTDescriptor.metal:197-222.  INTERIOR (wave-uniform, almost
         // every descriptor): the sample and its four neighbours are inside the image, so the gradient is four loads at one
         // 32-bit offset (the rows above and below through an SGPR addend) and there is no per-sample range test or mirror.
+#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1             // tools: every histogram add replaced by register arithmetic (the loop without its LDS atomics)
+        unsigned long long abl_acc = 0ull;
+#define DESC_HADD(p, v) (abl_acc ^= (v) + (unsigned long long)(size_t)(p))
+#else
+#define DESC_HADD(p, v) atomicAdd((p), (v))
+#endif
         auto sample = [&](auto interior_tag, int j, int i, float t_xp, float t_xm, float t_yp, float t_ym) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
             const float fj = (float)j, fi = (float)i;
@@ -1115,12 +1121,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
             }
             // gradient (tx, ty) = (dx, dy) / 2 (SIFTGradient.metal:31-32), angle atan2(tx, ty), orientation = angle - theta: the
             // vector (x = ty, y = tx) rotated by -theta; its direction does not depend on the factor 1/2
+#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 2             // tools: the loop without its gradient / angle / weight arithmetic (loads, walk and the 8 atomics stay)
+            const float bin = fminf(fabsf(dx) * 8.0f, 7.5f);
+            const float v32 = fabsf(dy) * 2147483648.0f;
+#else
             const float xr = fmaf(dy, cosT, dx * sinT), yr = fmaf(dx, cosT, -(dy * sinT));
             const float bin = octant_bin(yr, xr);                          // in [0, 8]
             // value = |gradient| exp(-(rx^2 + ry^2) / 8) in units of 2^-32: |gradient| = sqrt(dx^2 + dy^2) / 2
             // (the factor -1/8 is a power of two: folding it into log2(e) gives the bits of __expf(-(rx^2 + ry^2) / 8))
             const float wgt = __builtin_amdgcn_exp2f(fmaf(rx, rx, ry * ry) * (-0.125f * 1.44269504088896341f));
             const float v32 = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * (wgt * 2147483648.0f);
+#endif
             {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
                 // and bin wrap (:59-79); here one test per cell corner, the two orientation bins wrapped once (bin lies in
                 // [0, 8]: floor can reach 8, never go negative).
@@ -1136,10 +1147,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
                 const float va = bMin * v32, vb = bMax * v32;              // the value's share of either orientation bin
                 const int c00 = (cay * 32 + cax * 8) * NCOPY;              // u64 index of cell (cax, cay), bin 0, copy 0
                 unsigned long long *pa = patch + c00 + ba * NCOPY, *pb = patch + c00 + bb * NCOPY;
-                if (xa && ya) { const float wxy = iMin * jMin; atomicAdd(pa, fix32_product(wxy, va)); atomicAdd(pb, fix32_product(wxy, vb)); }
-                if (xb && ya) { const float wxy = iMax * jMin; atomicAdd(pa + 8 * NCOPY, fix32_product(wxy, va)); atomicAdd(pb + 8 * NCOPY, fix32_product(wxy, vb)); }
-                if (xb && yb) { const float wxy = iMax * jMax; atomicAdd(pa + 40 * NCOPY, fix32_product(wxy, va)); atomicAdd(pb + 40 * NCOPY, fix32_product(wxy, vb)); }
-                if (xa && yb) { const float wxy = iMin * jMax; atomicAdd(pa + 32 * NCOPY, fix32_product(wxy, va)); atomicAdd(pb + 32 * NCOPY, fix32_product(wxy, vb)); }
+                if (xa && ya) { const float wxy = iMin * jMin; DESC_HADD(pa, fix32_product(wxy, va)); DESC_HADD(pb, fix32_product(wxy, vb)); }
+                if (xb && ya) { const float wxy = iMax * jMin; DESC_HADD(pa + 8 * NCOPY, fix32_product(wxy, va)); DESC_HADD(pb + 8 * NCOPY, fix32_product(wxy, vb)); }
+                if (xb && yb) { const float wxy = iMax * jMax; DESC_HADD(pa + 40 * NCOPY, fix32_product(wxy, va)); DESC_HADD(pb + 40 * NCOPY, fix32_product(wxy, vb)); }
+                if (xa && yb) { const float wxy = iMin * jMax; DESC_HADD(pa + 32 * NCOPY, fix32_product(wxy, va)); DESC_HADD(pb + 32 * NCOPY, fix32_product(wxy, vb)); }
             }
         };
         auto walk = [&](auto interior_tag) {
@@ -1152,6 +1163,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
             }
             int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
             auto locate = [&](int idx, int &j, int &i) {                   // j: x offset (inner), i: y offset (outer); idx never decreases
+#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 3             // tools: the walk without its LDS table (other samples, about as many)
+                { const int hs = (side * 45) >> 6; const int ii = (int)(((float)idx + 0.5f) * (1.0f / (float)max(hs, 1))); i = min(ii - radius + ((side - hs) >> 1), radius); j = idx - ii * hs - (hs >> 1); return; }
+#endif
                 if (compact) {
                     while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty rows have equal starts
                     i = cur - radius;
@@ -1194,6 +1208,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
             }
         };
         if (interior) walk(std::true_type{}); else walk(std::false_type{});
+#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1
+        if (abl_acc == 0x123456789abcdefull) atomicAdd(patch, abl_acc);
+#endif
+#undef DESC_HADD
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
         __threadfence_block();
         unsigned long long a0 = 0ull, a1 = 0ull;                           // bins lane and lane + 64: their NCOPY copies are adjacent

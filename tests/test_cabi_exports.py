@@ -119,7 +119,13 @@ def test_swift_stub_files_match_integration_md():
     sw = os.path.join(ROOT, "swift", "Sources")
     assert open(os.path.join(sw, "CSiftmi", "module.modulemap")).read() == modmap[0]
     assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X.swift")).read() == swift[0]
-    assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Match.swift")).read() == "import CSiftmi\n\n" + swift[1]
+    assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Match.swift")).read() == "import CSiftmi\nimport Foundation\n\n" + swift[1]
+    # the reference's matchers are statics of the value type and its call sites (DescriptorTests.swift:141-169) name no device: the stub
+    # must offer exactly those signatures (an instance method on SIFT did not compile against `SIFTDescriptor.match(source:...)`)
+    ext = swift[1][swift[1].index("extension SIFTDescriptor {"):swift[1].index("extension SIFT {")]
+    for name, dflt in (("match", "1.176"), ("approximateMatch", "300"), ("matchGeometry", "1.176")):
+        assert re.search(r"public static func %s\(source: \[SIFTDescriptor\], target: \[SIFTDescriptor\],\s*absoluteThreshold: Float = %s, relativeThreshold: Float = 0.6\)" % (name, re.escape(dflt)), ext), name
+    assert "-> [SIFTCorrespondence]" in ext and "-> Float" in ext
     assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Stream.swift")).read() == swift[2]
     # every siftmi_* symbol the Swift uses is declared in the header
     hdr = open(os.path.join(ROOT, "include", "siftmi.h")).read()

@@ -86,7 +86,7 @@ def test_transcription_agrees_with_oracle_orientation_stage(butterfly_run):
     assert n_kp > 1200 and n_angles > 1350
     # numpy's float32 arctan2 and glibc's atan2f differ in the last bit here and there; where such an angle sits on a bin boundary
     # the sample moves to the neighbouring bin and the interpolated peak by up to ~1.5e-3 rad (the same keypoint, the same 1.52e-3,
-    # shows up between the HIP path and the oracle: profiles/desc_margin_r02.log).  All other angles agree to float noise.
+    # shows up between the HIP path and the oracle: profiles/archive/desc_margin_r02.log).  All other angles agree to float noise.
     assert worst <= 2e-3, worst
     assert n_loose <= 6, n_loose                # observed 3 of 1.4 k angles
     assert hist_rel <= 5e-3, hist_rel           # one moved sample of a ~300-sample window
