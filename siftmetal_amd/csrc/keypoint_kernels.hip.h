@@ -970,8 +970,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 // WPB = wavefronts per workgroup (COOP = false only): 4, or 1 -- a workgroup's LDS and wave slots are held until its LAST wavefront is
 // done, and descriptors differ 4x in their sample count, so with four independent wavefronts per workgroup a quarter of the slots
 // idles at workgroup tails on dense frames (4.35 of 6 resident, PMC round 4)
+#ifndef SIFTMI_DESC_WAVES
+#define SIFTMI_DESC_WAVES 7                                // wavefronts per SIMD the descriptor kernel's register budget is sized for (72 VGPRs)
+#endif
 template <bool COOP, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI_DESC_WAVES))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
                                                         float *__restrict__ desc_f32 /* may be null */) {
@@ -988,6 +991,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
     __shared__ unsigned long long patch_all[WPB][NCOPY * DESC_N];
     __shared__ int col_start_all[WPB][MAXCOL + 1];
     __shared__ short col_lo_all[WPB][MAXCOL];
+    __shared__ short col_len_all[WPB][MAXCOL];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hw_ = COOP ? 0 : wv;                          // whose histogram copies: the workgroup's (COOP) or this wave's
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
@@ -996,6 +1000,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
     unsigned long long *patch = patch0 + (lane & (NCOPY - 1));           // this lane's copy; bin slot k sits at patch[k * NCOPY]
     int *col_start = col_start_all[wv];
     short *col_lo = col_lo_all[wv];
+    short *col_len = col_len_all[wv];
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(desc_count[group], P.cap_desc[o]);
     const int w = P.w[o], h = P.h[o];
@@ -1043,7 +1048,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
         // (u64 fixed point), so walking row-major instead of the reference's column-major changes nothing -- but
         // neighbouring lanes then read neighbouring pixels: the four gradient loads of a wavefront touch 3-4 cache
         // lines instead of 64 each (round 1 walked columns: every lane its own line, the texture path was the limit).
+        // Round 5: an INTERIOR window is walked in QUADS -- four consecutive candidates of a row per lane and trip (the last quad of a
+        // row is partly past its interval; those samples are given an x offset that fails the exact test).  The walk's table look-up
+        // and the loads' address arithmetic are then paid once per four samples, the row's texels arrive as four wide loads instead of
+        // sixteen dword loads, and the terms of the rotated coordinates that depend on the row alone are shared; the exact per-sample
+        // arithmetic is unchanged, so the same samples add the same values (order-free bins: bit-identical descriptors).  The loop is
+        // bound by vector issue (ablation, profiles/desc_ablation_r05.log: without its LDS atomics it is no faster), ~150 -> ~125
+        // instructions per sample.
         const bool compact = side <= MAXCOL;
+        const int unit = (compact && interior) ? 4 : 1;                   // candidates per walk index
         int total;
         if (compact) {
             const float Lh = 2.5f * histogramWidth;
@@ -1071,10 +1084,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
                     hi = min(radius, (int)ceilf(a1));
                 }
                 const int len = max(hi - lo + 1, 0);
-                int incl = len;                                            // inclusive wave prefix sum
+                const int nun = unit == 4 ? (len + 3) >> 2 : len;          // walk indices of this row
+                int incl = nun;                                            // inclusive wave prefix sum
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-                if (cidx < side) { col_start[cidx] = run + incl - len; col_lo[cidx] = (short)lo; }
+                if (cidx < side) { col_start[cidx] = run + incl - nun; col_lo[cidx] = (short)lo; col_len[cidx] = (short)len; }
                 run += __shfl(incl, 63);
             }
             total = run;
@@ -1090,7 +1104,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
         // 32-bit offset (the rows above and below through an SGPR addend) and there is no per-sample range test or mirror.
 #if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1             // tools: every histogram add replaced by register arithmetic (the loop without its LDS atomics)
         unsigned long long abl_acc = 0ull;
-#define DESC_HADD(p, v) (abl_acc ^= (v) + (unsigned long long)(size_t)(p))
+#define DESC_HADD(p, v) do { const unsigned long long v_ = (v); asm volatile("; histogram add elided" :: "v"((unsigned)v_), "v"((unsigned)(size_t)(p))); } while (0)
 #else
 #define DESC_HADD(p, v) atomicAdd((p), (v))
 #endif
@@ -1121,17 +1135,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
             }
             // gradient (tx, ty) = (dx, dy) / 2 (SIFTGradient.metal:31-32), angle atan2(tx, ty), orientation = angle - theta: the
             // vector (x = ty, y = tx) rotated by -theta; its direction does not depend on the factor 1/2
-#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 2             // tools: the loop without its gradient / angle / weight arithmetic (loads, walk and the 8 atomics stay)
-            const float bin = fminf(fabsf(dx) * 8.0f, 7.5f);
-            const float v32 = fabsf(dy) * 2147483648.0f;
-#else
             const float xr = fmaf(dy, cosT, dx * sinT), yr = fmaf(dx, cosT, -(dy * sinT));
             const float bin = octant_bin(yr, xr);                          // in [0, 8]
             // value = |gradient| exp(-(rx^2 + ry^2) / 8) in units of 2^-32: |gradient| = sqrt(dx^2 + dy^2) / 2
             // (the factor -1/8 is a power of two: folding it into log2(e) gives the bits of __expf(-(rx^2 + ry^2) / 8))
             const float wgt = __builtin_amdgcn_exp2f(fmaf(rx, rx, ry * ry) * (-0.125f * 1.44269504088896341f));
             const float v32 = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * (wgt * 2147483648.0f);
-#endif
             {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
                 // and bin wrap (:59-79); here one test per cell corner, the two orientation bins wrapped once (bin lies in
                 // [0, 8]: floor can reach 8, never go negative).
@@ -1163,9 +1172,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
             }
             int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
             auto locate = [&](int idx, int &j, int &i) {                   // j: x offset (inner), i: y offset (outer); idx never decreases
-#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 3             // tools: the walk without its LDS table (other samples, about as many)
-                { const int hs = (side * 45) >> 6; const int ii = (int)(((float)idx + 0.5f) * (1.0f / (float)max(hs, 1))); i = min(ii - radius + ((side - hs) >> 1), radius); j = idx - ii * hs - (hs >> 1); return; }
-#endif
                 if (compact) {
                     while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty rows have equal starts
                     i = cur - radius;
@@ -1176,12 +1182,47 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6))) v
                 }
             };
             if constexpr (INTERIOR) {
-                // Software-pipelined (round 4): the four texels of the NEXT candidate are requested before the current one is
-                // turned into its eight histogram adds, so a lane's memory latency runs under ~130 vector instructions and the LDS
-                // atomics of the sample before instead of in front of them.  The request is unconditional (past the last candidate
-                // the last one is fetched again; a candidate that fails the cell-range test below costs four L2 hits): no branch
-                // around a vector-memory instruction, so the compiler's vmcnt count stays exact (vmcnt(4) at the use).
                 if (lidx >= total) return;
+                if (compact) {
+                    // quads: row y holds texels x - 1 ... x + 4 of the quad's four samples x ... x + 3 (b128 + b64), rows y - 1 and y + 1
+                    // texels x ... x + 3 (b128 each).  A partial last quad reads up to three texels past its row's interval -- inside the
+                    // image row, the next row, or past the layer's end where the range-checked buffer returns 0 -- and never uses them.
+                    // No software pipelining here: a trip is ~420 vector instructions, the other six wavefronts of the SIMD cover its
+                    // one memory latency, and the 14 registers a prefetched quad would hold are the seventh wavefront (measured equal
+                    // or 1-2 % behind with the prefetch, profiles/desc_variants_r05.log).
+                    auto locate_q = [&](int q, int &j0, int &i, int &nv) {
+                        while (q >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }
+                        const int k4 = (q - cur_start) << 2;
+                        i = cur - radius;
+                        j0 = (int)col_lo[cur] + k4;
+                        nv = (int)col_len[cur] - k4;                           // >= 1 candidates from j0 on in this row
+                    };
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    auto fetch_q = [&](int j0, int i, u32x4 &a, u32x2 &a2, u32x4 &u, u32x4 &d) {
+                        const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j0 - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
+                        a = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);
+                        a2 = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);
+                        u = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);
+                        d = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);
+                    };
+                    for (int q = lidx; q < total; q += STRIDE) {
+                        int j0, i, nv;
+                        u32x4 a, u, d;
+                        u32x2 a2;
+                        locate_q(q, j0, i, nv);
+                        fetch_q(j0, i, a, a2, u, d);
+                        const float A[6] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                                            __uint_as_float(a2.x), __uint_as_float(a2.y)};
+                        const float U[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+                        const float D[4] = {__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w)};
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++)
+                            sample(interior_tag, s4 < nv ? j0 + s4 : 30000, i, A[s4 + 2], A[s4], D[s4], U[s4]);
+                    }
+                    return;
+                }
+                // (windows wider than the walk's table -- never with the default schedule): one sample per trip, its texels requested a trip ahead
                 auto fetch = [&](int j, int i, float &t_xp, float &t_xm, float &t_yp, float &t_ym) {
                     const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
                     t_xp = layer_ld_s(g, c + 8, g.pitch); t_xm = layer_ld_s(g, c, g.pitch);
