@@ -78,7 +78,7 @@ def match_extra(eng, local_rank):
     import siftmetal_amd as sm
     out = {}
     rng = np.random.default_rng(0)
-    for ns, nt in ((20000, 20000), (100000, 100000), (200000, 200000)):
+    for ns, nt in ((2500, 2300), (20000, 20000), (100000, 100000), (200000, 200000)):
         tgt = np.zeros(nt, sm.descriptor_dtype)
         tgt["features"] = np.clip(np.abs(rng.normal(0, 40, (nt, 128))), 0, 255)
         src = np.zeros(ns, sm.descriptor_dtype)
@@ -96,11 +96,32 @@ def match_extra(eng, local_rank):
             call()
         dt = (time.perf_counter() - t0) / reps
         tf = ns * nt * 256 / dt / 1e12
-        out["%dk_x_%dk" % (ns // 1000, nt // 1000)] = {"ms_per_call": round(dt * 1e3, 4), "Gpairs_per_s": round(ns * nt / dt / 1e9, 1), "matches": int(n.value),
-                                                      "int8_TFLOPs": round(tf, 1), "frac_of_int8_mfma_peak": round(tf / MFMA_I8_DENSE_PEAK_TFLOPS, 4)}
-        d_src.close(); d_tgt.close()
+        # the device-resident variant: matches packed in source order + their count stay in HBM, calls queued without a host synchronisation
+        d_out = smstream.DeviceFrames(np.zeros(ns * 12 + 4, np.uint8), local_rank)
+
+        def call_dev():
+            eng.match_device(d_src.ptr, ns, d_tgt.ptr, nt, d_out.ptr + 4, d_out.ptr)
+
+        call_dev()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call_dev()
+        eng.synchronize()
+        dtd = (time.perf_counter() - t0) / reps
+        cnt = np.zeros(1, np.int32)
+        _capi.check(eng.L.siftmi_memcpy(cnt.ctypes.data, d_out.ptr, 4, 1))
+        if int(cnt[0]) != int(n.value):
+            raise SystemExit("bench: the device-resident matcher found %d matches, the host call %d" % (int(cnt[0]), int(n.value)))
+        tfd = ns * nt * 256 / dtd / 1e12
+        key = "%dk_x_%dk" % (ns // 1000, nt // 1000) if ns >= 10000 else "%d_x_%d" % (ns, nt)
+        out[key] = {"ms_per_call": round(dt * 1e3, 4), "Gpairs_per_s": round(ns * nt / dt / 1e9, 1), "matches": int(n.value),
+                    "int8_TFLOPs": round(tf, 1), "frac_of_int8_mfma_peak": round(tf / MFMA_I8_DENSE_PEAK_TFLOPS, 4),
+                    "device_output_ms_per_call": round(dtd * 1e3, 4), "device_output_frac_of_int8_mfma_peak": round(tfd / MFMA_I8_DENSE_PEAK_TFLOPS, 4)}
+        d_src.close(); d_tgt.close(); d_out.close()
     out["workload"] = ("siftmi_match_descriptors (brute force + ratio test, SIFTDescriptor.match), descriptors resident in HBM, whole call incl. the host copy of "
-                       "the match records; bound = int8 MFMA, peak %.0f TFLOP/s dense" % MFMA_I8_DENSE_PEAK_TFLOPS)
+                       "the match records; device_output_*: siftmi_match_descriptors_device, matches packed in source order + count left in HBM, %d calls queued and "
+                       "one synchronisation; bound = int8 MFMA, peak %.0f TFLOP/s dense" % (10, MFMA_I8_DENSE_PEAK_TFLOPS))
     return out
 
 
@@ -157,6 +178,9 @@ def cpu_baseline(frames, seconds_budget=18.0):
     pyoracle.set_num_threads(cores)
     out["single_thread"] = {"value": round(W * H / dt1 / 1e6, 4), "unit": "Mpixels/s", "cores": 1,
                             "sample": "1 frame, %.1f s, %d descriptors" % (dt1, n_desc1)}
+    # how many single threads the all-cores figure is worth: the literal restatement is memory-bound (every stage is a full pass over
+    # 1.1 GB of f32 stacks per frame, no fusion) long before the cores run out -- a baseline figure, not a tuned CPU SIFT
+    out["cores_effective"] = round(out["value"] / out["single_thread"]["value"], 1) if out["single_thread"]["value"] > 0 else None
     return out
 
 

@@ -406,6 +406,14 @@ int siftmi_match_descriptors(siftmi_ctx *ctx, const siftmi_descriptor *source, i
                              const siftmi_descriptor *target, int64_t n_target, int on_device,
                              float absolute_threshold, float relative_threshold,
                              const siftmi_match **matches, int64_t *count);
+/* The same match with everything staying in HBM: descriptors in device memory, the records of the matched sources packed in source
+   order into d_matches (device, capacity n_source records) and their number into *d_count (device); asynchronous on `stream`
+   (hipStream_t, NULL = the context's stream), no host synchronisation -- a consumer on the device (RANSAC, a tracker) reads them from
+   there, a host reads *d_count when it needs it.  Scratch is the context's: calls on one context are ordered on the device. */
+int siftmi_match_descriptors_device(siftmi_ctx *ctx, const siftmi_descriptor *d_source, int64_t n_source,
+                                    const siftmi_descriptor *d_target, int64_t n_target,
+                                    float absolute_threshold, float relative_threshold,
+                                    siftmi_match *d_matches, int32_t *d_count, void *stream);
 /* How siftmi_match_descriptors cuts a problem of this size (no reference counterpart; for tests and tuning): targets per chunk, chunks,
    and whether the chunks start from a bound (a pre-pass over the first 512 targets + the bests earlier chunks have published)
    instead of from "no best".  The results do not depend on any of it. */

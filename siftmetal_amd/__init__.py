@@ -234,6 +234,11 @@ class Engine:
             return np.zeros(0, _capi.match_dtype)
         return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 12,)).view(_capi.match_dtype).copy()
 
+    def match_device(self, d_source, n_source, d_target, n_target, d_matches, d_count, absolute_threshold=1.176, relative_threshold=0.6, stream=None):
+        """siftmi_match_descriptors_device: all pointers are device addresses (ints); asynchronous, nothing is synchronised."""
+        _capi.check(self.L.siftmi_match_descriptors_device(self.h, d_source, n_source, d_target, n_target, absolute_threshold, relative_threshold,
+                                                          d_matches, d_count, stream))
+
     def match_plan(self, n_source, n_target):
         """(targets per chunk, chunks, chunks start from a bound) for a problem of this size (siftmi_match_plan)."""
         sl, ns, b = C.c_int64(), C.c_int64(), C.c_int()

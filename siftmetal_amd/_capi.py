@@ -15,7 +15,7 @@ T_NAMES = ["seed", "blur", "downsample", "extrema", "refine", "sort", "orient", 
 EXPORTS = [
     "siftmi_default_config", "siftmi_create", "siftmi_destroy", "siftmi_last_error", "siftmi_device_count",
     "siftmi_detect", "siftmi_describe", "siftmi_detect_describe_batch", "siftmi_detect_describe_batch_device",
-    "siftmi_descriptor_to_reference", "siftmi_host_alloc", "siftmi_host_free", "siftmi_match_descriptors", "siftmi_match_plan", "siftmi_approximate_match", "siftmi_match_geometry", "siftmi_descriptor_index", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
+    "siftmi_descriptor_to_reference", "siftmi_host_alloc", "siftmi_host_free", "siftmi_match_descriptors", "siftmi_match_descriptors_device", "siftmi_match_plan", "siftmi_approximate_match", "siftmi_match_geometry", "siftmi_descriptor_index", "siftmi_get_stats", "siftmi_octave_size", "siftmi_get_sigma",
     "siftmi_get_weights", "siftmi_copy_gaussian", "siftmi_copy_dog", "siftmi_copy_extrema", "siftmi_copy_orientations",
     "siftmi_copy_descriptor_floats", "siftmi_enable_timings", "siftmi_reset_timings", "siftmi_get_timings",
     "siftmi_blur_algorithmic_bytes", "siftmi_get_blur_layer_timings", "siftmi_time_blur", "siftmi_time_copy", "siftmi_time_blur_memory", "siftmi_synchronize",
@@ -125,6 +125,7 @@ def load():
     L.siftmi_detect_describe_batch_device.argtypes = [vp, C.c_int32, vp, C.c_int, C.c_size_t, C.c_size_t,
                                                       vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
     L.siftmi_match_descriptors.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.siftmi_match_descriptors_device.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp]
     L.siftmi_match_plan.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.siftmi_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.siftmi_host_free.argtypes = [vp]

@@ -358,10 +358,13 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
 }
 
 // splits combine in target order; thresholds as SIFTDescriptor.swift:349-355
+// block_count (or null): the number of matched sources of every 256-source block, for match_compact_kernel
 __global__ __launch_bounds__(256) void match_finalize_kernel(const int4 *__restrict__ part, int n_split, const int *__restrict__ src_norm, int n_src,
-                                                            float abs_thr, float rel_thr, MatchRec *__restrict__ out) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_src) return;
+                                                            float abs_thr, float rel_thr, MatchRec *__restrict__ out, int32_t *__restrict__ block_count) {
+    __shared__ int s_hits;
+    if (block_count) { if (threadIdx.x == 0) s_hits = 0; __syncthreads(); }
+    const int s = min((int)(blockIdx.x * 256 + threadIdx.x), n_src - 1);        // (lanes past the end repeat the last source and write nothing)
+    const bool live = (int)(blockIdx.x * 256 + threadIdx.x) < n_src;
     int best = MM_NONE, idx = -1, second = MM_NONE;
     // eight splits' records requested together, combined in order (one at a time the loop is a chain of memory latencies: 26 us
     // for 20k sources x 10 splits)
@@ -381,7 +384,42 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const int4 *__restr
         rec.distance = bd;
         if (bd < abs_thr && bd < sd * rel_thr) rec.target = idx;
     }
-    out[s] = rec;
+    if (live) out[s] = rec;
+    if (block_count) {
+        const unsigned long long b = __ballot(live && rec.target >= 0);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&s_hits, __popcll(b));
+        __syncthreads();
+        if (threadIdx.x == 0) block_count[blockIdx.x] = s_hits;
+    }
+}
+
+// Device-resident result (siftmi_match_descriptors_device): the records of the matched sources, in source order, packed into the caller's
+// buffer, and their number -- the reference's output array (SIFTDescriptor.swift:304-317 appends in source order) without a host round
+// trip.  A block's offset is the sum of the per-block match counts match_finalize_kernel left (n / 256 values), then a ballot scan
+// inside the block; the last block writes the total.
+__global__ __launch_bounds__(256) void match_compact_kernel(const MatchRec *__restrict__ all, int n_src, const int32_t *__restrict__ block_count,
+                                                           MatchRec *__restrict__ out, int32_t *__restrict__ count) {
+    __shared__ int wsum[4], s_before;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int before = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) before += block_count[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) wsum[wv] = before;
+    __syncthreads();
+    if (tid == 0) s_before = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int s = blockIdx.x * 256 + tid;
+    MatchRec rec; rec.source = s; rec.target = -1; rec.distance = 0.0f;
+    if (s < n_src) rec = all[s];
+    const bool hit = rec.target >= 0;
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) wsum[wv] = __popcll(b);
+    __syncthreads();
+    int pos = s_before + __popcll(b & ((1ull << lane) - 1ull));
+    for (int k = 0; k < wv; k++) pos += wsum[k];
+    if (hit) out[pos] = rec;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = s_before + wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 }  // namespace siftmi

@@ -1566,6 +1566,57 @@ extern "C" int siftmi_match_plan(int64_t n_source, int64_t n_target, int64_t *sp
     return SIFTMI_OK;
 }
 
+// The matcher's launch sequence on `st`: leaves one record per source (target -1 = no match) in c->d_match_out.  d_src / d_tgt: device memory.
+static int enqueue_match(siftmi_ctx *c, hipStream_t st, const DescriptorRec *d_src, int64_t n_source, const DescriptorRec *d_tgt, int64_t n_target,
+                         float absolute_threshold, float relative_threshold, int32_t **block_count_out = nullptr) {
+    auto grow = [&](void **p, long long *cap, long long need, size_t elem) -> int {
+        if (need <= *cap) return SIFTMI_OK;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; *cap = 0;
+        HIP_TRY(hipMalloc(p, (size_t)need * elem));
+        *cap = need;
+        return SIFTMI_OK;
+    };
+    int rc;
+    const MatchPlan plan = match_plan(n_source, n_target);
+    const long long groups = plan.groups, split_len = plan.split_len, n_split = plan.n_split;
+    if (n_split > 65535) return set_error(SIFTMI_E_BADARG, "too many target splits");
+    // scratch: packed int8 rows + norms for both sides, per-split partial results (one allocation)
+    const long long n_blocks = (n_source + 255) / 256;
+    const long long words = n_source * 33 + n_target * 33 + (n_split + 1) * n_source * 4 + n_blocks + 64;
+    if ((rc = grow((void **)&c->d_match_scratch, &c->match_scratch_cap, words, sizeof(int)))) return rc;
+    if ((rc = grow((void **)&c->d_match_out, &c->match_out_cap, n_source, sizeof(MatchRec)))) return rc;
+    int *src_packed = c->d_match_scratch;                               // 16-byte aligned pieces first
+    int *tgt_packed = src_packed + n_source * 32;
+    int4 *part = (int4 *)(tgt_packed + n_target * 32);
+    int4 *bound = part + n_split * n_source;                            // the pre-pass's records
+    int *src_norm = (int *)(bound + n_source);
+    int *tgt_norm = src_norm + n_source;
+    int32_t *block_count = tgt_norm + n_target;                         // matches per 256-source block (device-resident variant)
+    if (block_count_out) *block_count_out = block_count;
+    {
+        const unsigned sb = (unsigned)((n_source * 32 + 255) / 256), tb = (unsigned)((n_target * 32 + 255) / 256);
+        hipLaunchKernelGGL(match_prep_kernel, dim3(sb + tb), dim3(256), 0, st, d_src, (int)n_source, src_packed, src_norm, (int)sb, d_tgt, (int)n_target,
+                           tgt_packed, tgt_norm);
+    }
+    // starting bound of the chunks (match_kernels.hip.h, round 4): a pre-pass over the first 512 targets, then the chunks.  Short
+    // chunks go without: the bound's set-up (a clear of `part`, a dependent launch) costs what it saves there.
+    const long long pre_len = 512;
+    const bool bounded = plan.bounded;
+    static_assert(512 % MM_SPLIT_QUANTUM == 0, "the pre-pass is one split of its own");
+    if (bounded) {
+        HIP_TRY(hipMemsetAsync(part, 0x7f, (size_t)n_split * (size_t)n_source * sizeof(int4), st));   // "none" (0x7f7f7f7f) until a block publishes
+        hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, 1), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
+                           (int)std::min<long long>(n_target, pre_len), (int)pre_len, bound, (const int4 *)nullptr);
+    }
+    hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, (unsigned)n_split), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
+                       (int)n_target, (int)split_len, part, bounded ? bound : (const int4 *)nullptr);
+    hipLaunchKernelGGL(match_finalize_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, part, (int)n_split, src_norm, (int)n_source,
+                       absolute_threshold, relative_threshold, c->d_match_out, block_count_out ? block_count : (int32_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return SIFTMI_OK;
+}
+
 // SIFTDescriptor.match (SIFT/SIFTDescriptor.swift:298-361) -- see match_kernels.hip.h
 extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *source, int64_t n_source, const siftmi_descriptor *target,
                                         int64_t n_target, int on_device, float absolute_threshold, float relative_threshold,
@@ -1600,43 +1651,37 @@ extern "C" int siftmi_match_descriptors(siftmi_ctx *c, const siftmi_descriptor *
         HIP_TRY(hipMemcpyAsync(c->d_match_tgt, target, (size_t)n_target * sizeof(DescriptorRec), hipMemcpyHostToDevice, st));
         d_src = c->d_match_src; d_tgt = c->d_match_tgt;
     }
-    const MatchPlan plan = match_plan(n_source, n_target);
-    const long long groups = plan.groups, split_len = plan.split_len, n_split = plan.n_split;
-    if (n_split > 65535) return set_error(SIFTMI_E_BADARG, "too many target splits");
-    // scratch: packed int8 rows + norms for both sides, per-split partial results (one allocation)
-    const long long words = n_source * 33 + n_target * 33 + (n_split + 1) * n_source * 4 + 64;
-    if ((rc = grow((void **)&c->d_match_scratch, &c->match_scratch_cap, words, sizeof(int)))) return rc;
-    if ((rc = grow((void **)&c->d_match_out, &c->match_out_cap, n_source, sizeof(MatchRec)))) return rc;
-    int *src_packed = c->d_match_scratch;                               // 16-byte aligned pieces first
-    int *tgt_packed = src_packed + n_source * 32;
-    int4 *part = (int4 *)(tgt_packed + n_target * 32);
-    int4 *bound = part + n_split * n_source;                            // the pre-pass's records
-    int *src_norm = (int *)(bound + n_source);
-    int *tgt_norm = src_norm + n_source;
-    {
-        const unsigned sb = (unsigned)((n_source * 32 + 255) / 256), tb = (unsigned)((n_target * 32 + 255) / 256);
-        hipLaunchKernelGGL(match_prep_kernel, dim3(sb + tb), dim3(256), 0, st, d_src, (int)n_source, src_packed, src_norm, (int)sb, d_tgt, (int)n_target,
-                           tgt_packed, tgt_norm);
-    }
-    // starting bound of the chunks (match_kernels.hip.h, round 4): a pre-pass over the first 512 targets, then the chunks.  Short
-    // chunks go without: the bound's set-up (a clear of `part`, a dependent launch) costs what it saves there.
-    const long long pre_len = 512;
-    const bool bounded = plan.bounded;
-    static_assert(512 % MM_SPLIT_QUANTUM == 0, "the pre-pass is one split of its own");
-    if (bounded) {
-        HIP_TRY(hipMemsetAsync(part, 0x7f, (size_t)n_split * (size_t)n_source * sizeof(int4), st));   // "none" (0x7f7f7f7f) until a block publishes
-        hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, 1), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
-                           (int)std::min<long long>(n_target, pre_len), (int)pre_len, bound, (const int4 *)nullptr);
-    }
-    hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, (unsigned)n_split), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
-                       (int)n_target, (int)split_len, part, bounded ? bound : (const int4 *)nullptr);
-    hipLaunchKernelGGL(match_finalize_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, part, (int)n_split, src_norm, (int)n_source,
-                       absolute_threshold, relative_threshold, c->d_match_out);
-    HIP_TRY(hipGetLastError());
+    if ((rc = enqueue_match(c, st, d_src, n_source, d_tgt, n_target, absolute_threshold, relative_threshold))) return rc;
     if (int rcc = collect_matches(c, st, n_source)) return rcc;                        // source order (:304-314)
     *count = (int64_t)c->h_matches.size();
     if (matches) *matches = c->h_matches.data();
     return SIFTMI_OK;
+}
+
+// The same match with everything staying in HBM and no host synchronisation: descriptors in device memory, the matched records packed in
+// source order into d_matches (capacity n_source), their number in *d_count; asynchronous on `stream`.
+extern "C" int siftmi_match_descriptors_device(siftmi_ctx *c, const siftmi_descriptor *d_source, int64_t n_source, const siftmi_descriptor *d_target,
+                                               int64_t n_target, float absolute_threshold, float relative_threshold, siftmi_match *d_matches,
+                                               int32_t *d_count, void *stream) {
+    if (!c || !d_count || n_source < 0 || n_target < 0 || (n_source && (!d_source || !d_matches)) || (n_target && !d_target))
+        return set_error(SIFTMI_E_BADARG, "bad argument");
+    if (n_source > (1ll << 30) || n_target > (1ll << 30)) return set_error(SIFTMI_E_BADARG, "too many descriptors");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    int rc;
+    if ((rc = order_begin(c, st))) return rc;
+    if (n_source == 0 || n_target == 0) {                                    // no target: every match is nil (:340-346)
+        HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t), st));
+        return order_end(c, st);
+    }
+    int32_t *block_count = nullptr;
+    if ((rc = enqueue_match(c, st, (const DescriptorRec *)d_source, n_source, (const DescriptorRec *)d_target, n_target, absolute_threshold, relative_threshold,
+                            &block_count)))
+        return rc;
+    hipLaunchKernelGGL(match_compact_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, c->d_match_out, (int)n_source, block_count,
+                       (MatchRec *)d_matches, d_count);
+    HIP_TRY(hipGetLastError());
+    return order_end(c, st);
 }
 
 // SIFTDescriptor.approximateMatch (SIFT/SIFTDescriptor.swift:362-417) -- see trie_kernels.hip.h

@@ -674,6 +674,45 @@ def test_match_large_bounded_chunks_sampled_sources_vs_oracle(sm, n_src, n_tgt):
     assert len(want) > 0.9 * len(sample)
 
 
+@pytest.mark.parametrize("n_src,n_tgt", [(1, 1), (255, 40), (256, 257), (2500, 2300), (20000, 7000), (70001, 50003)])
+def test_match_device_output_equals_host_call(sm, n_src, n_tgt):
+    """siftmi_match_descriptors_device: descriptors in HBM, the matched records packed in source order into device memory and their
+    number beside them, no host synchronisation inside the call -- byte-equal to what siftmi_match_descriptors returns on the host
+    (which the other tests hold against the oracle's ordered scan), for block-boundary sizes, both launch plans, and repeated
+    asynchronous calls on one context into different output buffers."""
+    import ctypes as C
+    from siftmetal_amd import _capi, stream as smstream
+    rng = np.random.default_rng(n_src * 7 + n_tgt)
+    tgt = np.zeros(n_tgt, sm.descriptor_dtype)
+    tgt["features"] = np.clip(np.abs(rng.normal(0, 40, (n_tgt, 128))), 0, 255)
+    src = np.zeros(n_src, sm.descriptor_dtype)
+    pick = rng.integers(0, n_tgt, n_src)
+    src["features"] = np.clip(tgt["features"][pick].astype(np.int32) + rng.integers(-10, 11, (n_src, 128)), 0, 255)
+    src["features"][::3] = rng.integers(0, 256, (len(src["features"][::3]), 128))          # a third of the sources match nothing
+    eng = sm.Engine(64, 64, n_octaves=1)
+    want = eng.match(src, tgt)
+    assert 0 < len(want) < n_src or n_src < 4
+    d_src, d_tgt = smstream.DeviceFrames(src.view(np.uint8)), smstream.DeviceFrames(tgt.view(np.uint8))
+    outs = [smstream.DeviceFrames(np.full(n_src * 12 + 4, 0xee, np.uint8)) for _ in range(3)]
+    for o in outs:                                                                         # three calls queued back to back, then one synchronisation
+        eng.match_device(d_src.ptr, n_src, d_tgt.ptr, n_tgt, o.ptr + 4, o.ptr)
+    eng.synchronize()
+    for o in outs:
+        raw = np.empty(n_src * 12 + 4, np.uint8)
+        _capi.check(eng.L.siftmi_memcpy(raw.ctypes.data, o.ptr, raw.nbytes, 1))
+        n = int(raw[:4].view(np.int32)[0])
+        assert n == len(want)
+        assert raw[4:4 + 12 * n].tobytes() == want.tobytes()
+        assert (raw[4 + 12 * n:] == 0xee).all()                                            # nothing written past the matches
+    # no targets: count 0, asynchronous as well
+    eng.match_device(d_src.ptr, n_src, d_tgt.ptr, 0, outs[0].ptr + 4, outs[0].ptr)
+    eng.synchronize()
+    z = np.empty(4, np.uint8)
+    _capi.check(eng.L.siftmi_memcpy(z.ctypes.data, outs[0].ptr, 4, 1))
+    assert int(z.view(np.int32)[0]) == 0
+    eng.close()
+
+
 def test_match_ties_quirk_and_edges(sm):
     from oracle import pyoracle
     rng = np.random.default_rng(9)

@@ -28,7 +28,8 @@ def sync():
     _capi.check(L.siftmi_device_synchronize(0))
 
 
-for pipeline, sets, back in ((2, 4, 2), (2, 4, 3), (2, 6, 3), (2, 6, 4), (2, 8, 5), (1, 4, 2), (1, 4, 3), (3, 6, 4)):
+CASES = ((2, 4, 2), (2, 4, 3), (2, 6, 3), (1, 4, 2)) if os.environ.get('PROBE_SHORT') else ((2, 4, 2), (2, 4, 3), (2, 6, 3), (2, 6, 4), (2, 8, 5), (1, 4, 2), (1, 4, 3), (3, 6, 4))
+for pipeline, sets, back in CASES:
     eng = sm.Engine(W, H, n_octaves=4, max_batch=F)
     fs = smstream.FrameStream(eng, F, pipeline=pipeline, result_sets=sets)
 
@@ -45,5 +46,5 @@ for pipeline, sets, back in ((2, 4, 2), (2, 4, 3), (2, 6, 3), (2, 6, 4), (2, 8, 
         step()
     sync()
     ms = (time.perf_counter() - t) / steps * 1e3
-    print("%s frames: %d contexts, %d result sets, results read %d steps late: %.3f ms/step" % (kind, pipeline, fs.n_sets, back, ms), flush=True)
+    print("upload streams %s; %s frames: %d contexts, %d result sets, results read %d steps late: %.3f ms/step" % (os.environ.get("SIFTMI_UPLOAD_STREAMS", "default"), kind, pipeline, fs.n_sets, back, ms), flush=True)
     fs.close(); eng.close()
