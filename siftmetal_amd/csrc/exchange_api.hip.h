@@ -213,7 +213,13 @@ extern "C" void siftmi_exchange_destroy(siftmi_exchange *x) {
     (void)hipSetDevice(x->s->device);
     // a gather that can no longer complete (a peer is gone) must not hang the teardown: bounded, then aborted
     if (x->gstream && x->ev_wait && !x->failed) (void)exchange_drain(x, "the pending gathers at destroy");
-    if (x->gstream && x->failed) (void)hipStreamSynchronize(x->gstream);          // aborted collectives exit
+    if (x->gstream && x->failed) {                                                // aborted collectives exit; bounded all the same
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(x->gstream) == hipErrorNotReady &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < x->timeout_s)
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        (void)hipGetLastError();
+    }
     if (x->comm) (void)rccl().CommDestroy(x->comm);
     if (x->ev_wait) (void)hipEventDestroy(x->ev_wait);
     for (auto &g : x->g) {

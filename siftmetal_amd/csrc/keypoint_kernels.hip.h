@@ -868,8 +868,45 @@ __global__ __launch_bounds__(64 * WPB) void orientation_kernel(PyramidDesc P, De
                 const float m = wgt * magnitude;
                 atomicAdd(&hist[bin], fix32_product(m, 4294967296.0f));
             };
-            if (interior) { for (int idx = lidx; idx < total; idx += STRIDE) sample(std::true_type{}, idx); }
-            else          { for (int idx = lidx; idx < total; idx += STRIDE) sample(std::false_type{}, idx); }
+            if (interior) {
+                // Round 5: an interior window is walked in QUADS, as the descriptor's: four consecutive samples of a window row per lane
+                // and trip (the last quad of a row runs up to three columns past the window: those samples get weight 0).  The index
+                // arithmetic, the row term of the weight and the address are shared, the row's texels arrive as three wide loads and one
+                // b64 instead of sixteen dword loads; every sample's own arithmetic is the expression of `sample` above, so the same
+                // values go to the same bins (order-free u64 sums: identical histograms).
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const int qpr = (side + 3) >> 2, total_q = side * qpr;
+                const float inv_qpr = 1.0f / (float)qpr;
+                for (int q = lidx; q < total_q; q += STRIDE) {
+                    const int jj = (int)(((float)q + 0.5f) * inv_qpr), k4 = (q - jj * qpr) << 2;
+                    const int j = jj - r, i0 = k4 - r, nv = side - k4;                       // nv >= 1 samples of this row from i0 on
+                    const int c = __mul24(y + j - 1, g.pitch) + ((x + i0 - 1) << 2);       // texel (x + i0 - 1, y + j - 1)
+                    const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);           // row y + j: columns x + i0 - 1 ... + 2
+                    const u32x2 rb = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);       //            ... + 3, + 4
+                    const u32x4 ru = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);             // row y + j - 1: columns x + i0 ... + 3
+                    const u32x4 rd = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);   // row y + j + 1
+                    const float A[6] = {__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w),
+                                        __uint_as_float(rb.x), __uint_as_float(rb.y)};
+                    const float U[4] = {__uint_as_float(ru.x), __uint_as_float(ru.y), __uint_as_float(ru.z), __uint_as_float(ru.w)};
+                    const float D[4] = {__uint_as_float(rd.x), __uint_as_float(rd.y), __uint_as_float(rd.z), __uint_as_float(rd.w)};
+                    const float v = (float)j * inv_sigma, vv = v * v;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) {
+                        const float u = (float)(i0 + s4) * inv_sigma;
+                        const float wgt = s4 < nv ? __builtin_amdgcn_exp2f(fmaf(u, u, vv) * k_exp) : 0.0f;
+                        const float tx = (A[s4 + 2] - A[s4]) * 0.5f, ty = (D[s4] - U[s4]) * 0.5f;
+                        const float orientation = atan2_lean(tx, ty);
+                        const float magnitude = __builtin_amdgcn_sqrtf(fmaf(tx, tx, ty * ty));
+                        int bin = (int)roundf(orientation * (float)(ORI_BINS / (2.0 * 3.14159265358979323846)));
+                        if (bin < 0) bin += ORI_BINS;
+                        if (bin >= ORI_BINS) bin -= ORI_BINS;
+                        atomicAdd(&hist[bin], fix32_product(wgt * magnitude, 4294967296.0f));
+                    }
+                }
+            } else {
+                for (int idx = lidx; idx < total; idx += STRIDE) sample(std::false_type{}, idx);
+            }
         }
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the keypoint
         __threadfence_block();

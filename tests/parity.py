@@ -18,8 +18,9 @@ TOL_DESC_L2 = 1e-4         # pre-quantisation unit-norm float vector
 
 
 def bins_allowed(n_bins):
-    """Quantised bins that may differ (by 1) among n_bins compared: 0.1 %, rounded up."""
-    return int(-(-MAX_DESC_BIN_FRAC * n_bins // 1))
+    """Quantised bins that may differ (by 1) among n_bins compared: 0.1 % -- rounded UP to one whole bin only for comparisons of fewer than
+    1000 bins (a handful of descriptors may hold ONE knife-edge bin; round 4's rule rounded up at every size), down otherwise."""
+    return 1 if 0 < n_bins < 1000 else int(MAX_DESC_BIN_FRAC * n_bins)
 
 
 def prefilter_extrema(orc, o, ext, dog_threshold=0.0133, border=5):

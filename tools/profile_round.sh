@@ -69,7 +69,7 @@ if trace:
             rows_r.append({"octave": o, "layer": layer, "radius": R, "kernel": t[3][:60], "workgroups": t[0], "launches_in_trace": t[2], "avg_us": round(t[1] / 1e3, 2),
                            "GBps": round(nb / t[1], 1)})
     if ok and tot_ns > 0:
-        json.dump({"source": "rocprofv3 --kernel-trace of `bench.py --steps 3 --warmup 1 --no-cpu --no-extras --pipeline 1 --serial-graph` (rocprof_kernel_shapes_%s.csv)" % tag,
+        json.dump({"source": "rocprofv3 --kernel-trace of 'bench.py --steps 3 --warmup 1 --no-cpu --no-extras --pipeline 1 --serial-graph' (rocprof_kernel_shapes_%s.csv)" % tag,
                    "algorithmic_bytes_per_step": tot_b, "blur_ms_per_step": round(tot_ns / 1e6, 4), "GBps_all_layers": round(tot_b / tot_ns, 1),
                    "frac_all_layers": round(tot_b / tot_ns / 8000.0, 4), "GBps_octave0": round(o0_b / o0_ns, 1), "frac_octave0": round(o0_b / o0_ns / 8000.0, 4),
                    "peak_GBps": 8000.0, "launch_shapes": rows_r}, open(out + "/roofline_rocprof_%s.json" % tag, "w"), indent=1)
