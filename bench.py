@@ -184,6 +184,31 @@ def cpu_baseline(frames, seconds_budget=18.0):
     return out
 
 
+def bind_to_gpu_numa_node(props):
+    """Pins this rank's threads (and, by first touch, its page-locked frame buffers) to the NUMA node its GPU hangs off: with one rank
+    per GPU every rank streams 57 GB/s out of host DRAM, and a buffer on the other socket crosses the inter-socket links.  Returns
+    (node, previous affinity mask) or (None, None) when the topology cannot be read (then nothing is changed)."""
+    try:
+        if os.environ.get("SIFTMI_BENCH_NO_AFFINITY") == "1":
+            return None, None
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return None, None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        prev = os.sched_getaffinity(0)
+        cpus &= prev
+        if not cpus:
+            return None, None
+        os.sched_setaffinity(0, cpus)
+        return node, prev
+    except Exception:
+        return None, None
+
+
 def self_launch(args):
     """--gpus N > 1 without a torchrun environment: spawn the ranks (no GPU call has happened in this process)."""
     import torch
@@ -266,6 +291,7 @@ def main():
         local_rank = 0                                      # a launcher that shows every rank its own GPU only (HIP_VISIBLE_DEVICES per rank)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: local rank %d but only %d HIP device(s) visible" % (local_rank, torch.cuda.device_count()))
+    numa_node, prev_affinity = bind_to_gpu_numa_node(torch.cuda.get_device_properties(local_rank))     # before any page-locked allocation
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # SIFTMI_FORCE_GATHER=1 exercises the RCCL exchange with a single rank (smoke test on a 1-GPU box)
@@ -410,6 +436,7 @@ def main():
                                      "step's results are copied to page-locked host memory (copy started at submit time) and read %d steps late; every step is "
                                      "computed in full, the timed region ends with a device synchronisation" % back),
                       "h2d_bytes_per_step": int(hpin.nbytes), "d2h_bytes_per_step": d2h_bytes,
+                      "host_numa_node": numa_node,            # this rank's threads and frame buffers sit on its GPU's NUMA node (None: topology unreadable, nothing pinned)
                       "rccl_ranks": rccl_ranks,
                       "rccl_ranks_source": "ncclCommCount of the exchange's communicator (checked against WORLD_SIZE)" if use_dist else None,
                       "ranks_share_one_gpu": bool(args.share_gpu),
@@ -659,6 +686,8 @@ def main():
         dev_sync()
         d_dense.close()
     if rank == 0 and not args.no_cpu and world == 1:
+        if prev_affinity is not None:
+            os.sched_setaffinity(0, prev_affinity)           # the CPU baseline runs on every core of the host
         out["cpu_baseline"] = cpu_baseline(frames_np)
     # everything that can still write to fd 1 (RCCL prints its version banner when the communicator goes) is torn down BEFORE
     # stdout is restored: the contract is ONE JSON line
