@@ -2,7 +2,8 @@
 and the keypoint phase (refine ... pack) of a step as separate calls on separate streams, the keypoint stream restricted to
 a subset of the CUs (hipExtStreamCreateWithCUMask), so that the VALU-bound keypoint kernels cannot take the whole chip from
 the other context's HBM-bound dense kernels.  No torch.
-usage: SIFTMI_LIB=tools/tmp_variants/libsiftmi_exp.so python tools/cumask_experiment.py [dense]"""
+usage: tools/build_variant.sh exp -DSIFTMI_EXPERIMENT; SIFTMI_LIB=$PWD/tools/tmp_variants/libsiftmi_exp.so python tools/cumask_probe.py [dense]
+(round 5: re-run on DENSE frames, whose keypoint phase is half the step; complementary masks on both streams added)"""
 import ctypes as C
 import os
 import sys
@@ -92,9 +93,9 @@ def alt():
 print("two contexts, whole steps alternating on two streams: %.3f ms" % timeit(alt))
 ref = [c.totals_host() for c in cs]
 masks = {"all 256 CUs": [0xffffffff] * 8,
-         "first 64 bits": [0xffffffff] * 2 + [0] * 6, "first 128 bits": [0xffffffff] * 4 + [0] * 4,
-         "every 4th bit (64)": [0x11111111] * 8, "every 2nd bit (128)": [0x55555555] * 8, "3 of 4 bits (192)": [0x77777777] * 8,
-         "every 8th bit (32)": [0x01010101] * 8}
+         "first 128 bits": [0xffffffff] * 4 + [0] * 4,
+         "every 2nd bit (128)": [0x55555555] * 8, "3 of 4 bits (192)": [0x77777777] * 8, "every 4th bit (64)": [0x11111111] * 8,
+         "5 of 8 bits (160)": [0x1f1f1f1f] * 8, "3 of 8 bits (96)": [0x07070707] * 8}
 for name, words in masks.items():
     sK = masked_stream(words)
     print("   keypoint phase alone on [%s]: %.3f ms" % (name, timeit(lambda: cs[0].call(sK, 2), n=8, warm=3)))
@@ -107,4 +108,18 @@ for name, words in masks.items():
     print("two contexts, dense phases on one stream / keypoint phases on a stream with [%s]: %.3f ms" % (name, timeit(phased)))
     sync()
     assert all((c.totals_host() == r).all() for c, r in zip(cs, ref))
+    # the dense phases confined to the COMPLEMENT of the keypoint stream's CUs (no sharing at all)
+    comp = [(~wd) & 0xffffffff for wd in words]
+    if any(comp):
+        sDm = masked_stream(comp)
+
+        def phased2():
+            i = k[0] & 1
+            k[0] += 1
+            cs[i].call(sDm, 1)
+            cs[i].call(sK, 2)
+        print("two contexts, dense phases on the complement / keypoint phases on [%s]: %.3f ms" % (name, timeit(phased2)), flush=True)
+        sync()
+        assert all((c.totals_host() == r).all() for c, r in zip(cs, ref))
+        hip.hipStreamDestroy(sDm)
     hip.hipStreamDestroy(sK)
