@@ -44,7 +44,36 @@ struct KeypointRec {            // == siftmi_keypoint (include/siftmi.h), 44 byt
 };
 struct ExtremumRec { int32_t x, y, scale; };
 struct DescriptorRec { int32_t keypoint; float theta; uint8_t features[DESC_N]; };   // 136 bytes
-struct DescInput { int32_t keypoint; float theta; };
+// One descriptor to compute: (keypoint, theta) plus everything that depends on them alone -- evaluated ONCE, by one lane of
+// desc_derive_kernel (large launches) or expand_descriptors_kernel<true> (a frame or two).  Round 5; the descriptor kernel evaluated
+// cosf / sinf / powf and five divisions per descriptor on all 64 lanes of its wavefront.  Same functions on the same arguments:
+// byte-identical records (tools/dense_stage_times.py digests).  Dense frames: descriptor_kernel 5.89 -> 5.69-5.75 ms for a 46 us launch
+// (it touches 270 MB of record lines) and +8 us in the expansion.  48 bytes.
+struct alignas(16) DescInput {
+    int32_t keypoint; float theta;
+    float cosT, sinT;                  // cosf(theta), sinf(theta)
+    float hw, inv_hw;                  // histogramWidth = 3 sigma 2^(interval / intervals) and its IEEE reciprocal
+    float px, py;                      // (int)abs / delta (SIFTDescriptor.metal:140-141)
+    int32_t radius, scale;             // window radius; Gaussian layer
+    float inv_cos, inv_sin;            // 1 / cosT, 1 / sinT (the walk's row intervals)
+};
+__device__ __forceinline__ DescInput make_desc_input(const KeypointRec &kp, int keypoint, float theta, float delta, int scales_per_octave) {
+    DescInput d;
+    d.keypoint = keypoint; d.theta = theta;
+    const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;         // SIFTOctave.swift:417-418
+    d.px = (float)absoluteX / delta; d.py = (float)absoluteY / delta;       // metal :140-141
+    d.cosT = cosf(theta); d.sinT = sinf(theta);
+    const float interval = (float)kp.scale + kp.sub_scale;
+    const float intervals = (float)scales_per_octave;
+    const float sigma = 1.6f;
+    const float sc = sigma * powf(2.0f, interval / intervals);
+    d.hw = 3.0f * sc;
+    d.inv_hw = 1.0f / d.hw;
+    d.radius = (int)(d.hw * sqrtf(2.0f) * ((float)4 + 1.0f) * 0.5f + 0.5f);
+    d.scale = kp.scale;
+    d.inv_cos = 1.0f / d.cosT; d.inv_sin = 1.0f / d.sinT;                   // (unused where the component is ~0)
+    return d;
+}
 
 // Per-context tables handed to every keypoint-stage kernel by value (kernarg -> SGPRs).
 struct PyramidDesc {
@@ -982,7 +1011,11 @@ __global__ __launch_bounds__(64 * WPB) void orientation_kernel(PyramidDesc P, De
 // Exclusive scan of the orientation counts of one group -> descriptor inputs in keypoint order
 // (SIFTOctave.swift:411-424 expansion).  One 1024-thread workgroup per group; the scan is a wave-level shuffle scan plus the 16
 // wave totals (round 3; it was a 10-step Hillis-Steele scan through LDS with 20 barriers: 7 us on a single frame's chain).
-__global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P, const int32_t *__restrict__ kp_count,
+// DERIVE: the (keypoint, theta)-only terms of a descriptor (DescInput) are filled in here -- a frame or two; large launches leave them to
+// desc_derive_kernel (one lane per descriptor over the whole chip: here a group's ~15 k keypoints are 15 per thread of ONE workgroup).
+template <bool DERIVE>
+__global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P, DetectParams prm, const KeypointRec *__restrict__ kps,
+                                                                 const int32_t *__restrict__ kp_count,
                                                                  const int32_t *__restrict__ ori_count, const float *__restrict__ ori_angles,
                                                                  DescInput *__restrict__ desc_in, int32_t *__restrict__ desc_count,
                                                                  int32_t *__restrict__ oriented_count) {
@@ -1006,16 +1039,37 @@ __global__ __launch_bounds__(1024) void expand_descriptors_kernel(PyramidDesc P,
     __syncthreads();
     int pos = incl - sum, total = 0, total_ori = 0;
     for (int k = 0; k < 16; k++) { if (k < wv) pos += wsum[k]; total += wsum[k]; total_ori += wori[k]; }
+    const float delta = P.delta[o];
     for (int k = k0; k < k1; k++) {
         const int c = ori_count[kbase + k];
-        for (int t = 0; t < c; t++, pos++) {
-            if (pos < P.cap_desc[o]) {
-                DescInput d; d.keypoint = k; d.theta = ori_angles[(kbase + k) * ORI_BINS + t];
-                desc_in[dbase + pos] = d;
-            }
+        if (c <= 0) continue;
+        if (DERIVE) {
+            const KeypointRec kp = kps[kbase + k];
+            for (int t = 0; t < c; t++, pos++)
+                if (pos < P.cap_desc[o])
+                    desc_in[dbase + pos] = make_desc_input(kp, k, ori_angles[(kbase + k) * ORI_BINS + t], delta, prm.desc_scales_per_octave);
+        } else {
+            for (int t = 0; t < c; t++, pos++)
+                if (pos < P.cap_desc[o])                                     // (keypoint, theta): the record's first 8 bytes, one store
+                    *reinterpret_cast<float2 *>(&desc_in[dbase + pos]) = make_float2(__int_as_float(k), ori_angles[(kbase + k) * ORI_BINS + t]);
         }
     }
     if (threadIdx.x == 0) { desc_count[group] = total; oriented_count[group] = total_ori; }
+}
+
+// The remaining fields of the descriptor inputs expand_descriptors_kernel<false> listed: one lane per descriptor.
+__global__ __launch_bounds__(256) void desc_derive_kernel(PyramidDesc P, DetectParams prm, const KeypointRec *__restrict__ kps,
+                                                         const int32_t *__restrict__ desc_count, DescInput *__restrict__ desc_in) {
+    const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
+    const int n = min(desc_count[group], P.cap_desc[o]);
+    const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
+    const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
+    const float delta = P.delta[o];
+    for (int di = blockIdx.x * 256 + threadIdx.x; di < n; di += gridDim.x * 256) {
+        const float2 kt = *reinterpret_cast<const float2 *>(&desc_in[dbase + di]);
+        const int k = __float_as_int(kt.x);
+        desc_in[dbase + di] = make_desc_input(kps[kbase + k], k, kt.y, delta, prm.desc_scales_per_octave);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1078,27 +1132,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(desc_count[group], P.cap_desc[o]);
     const int w = P.w[o], h = P.h[o];
-    const float delta = P.delta[o];
-    const size_t kbase = (size_t)frame * P.kp_frame + P.kp_off[o];
     const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
     for (int di = COOP ? (int)blockIdx.x : (int)(blockIdx.x * WPB + wv); di < n; di += COOP ? (int)gridDim.x : (int)(gridDim.x * WPB)) {
-        const DescInput in = desc_in[dbase + di];
-        const KeypointRec kp = kps[kbase + in.keypoint];
+        const DescInput in = desc_in[dbase + di];                          // wave-uniform: scalar loads
         const float theta = in.theta;
-        const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // SIFTOctave.swift:417-418
-        const LayerView g = layer_view(layer_ptr(P, frame, o, kp.scale), w, h);
-        const float px = (float)absoluteX / delta, py = (float)absoluteY / delta;   // metal :140-141
-        const int d = 4;
-        const float cosT = cosf(theta), sinT = sinf(theta);
-        const float interval = (float)kp.scale + kp.sub_scale;
-        const float intervals = (float)prm.desc_scales_per_octave;
-        const float sigma = 1.6f;
-        const float sc = sigma * powf(2.0f, interval / intervals);
-        const float histogramWidth = 3.0f * sc;
-        const float inv_hw = 1.0f / histogramWidth;
-        const int radius = (int)(histogramWidth * sqrtf(2.0f) * ((float)d + 1.0f) * 0.5f + 0.5f);
+        const LayerView g = layer_view(layer_ptr(P, frame, o, in.scale), w, h);
+        const float px = in.px, py = in.py;
+        const float cosT = in.cosT, sinT = in.sinT;
+        const float histogramWidth = in.hw;
+        const int radius = in.radius;
         // per descriptor, hoisted out of the sample loop (float note above): the rotation with 1 / histogramWidth folded in
-        const float cs = cosT * inv_hw, sn = sinT * inv_hw;
+        const float cs = cosT * in.inv_hw, sn = sinT * in.inv_hw;
         // px, py are multiples of 2^-15 well below 2^22, so px + j is exact and ushort2(px + j, ...) truncates to (int)px + j
         // wherever px + j >= 0: integer sample coordinates, no conversions in the loop
         const int ipx = (int)px, ipy = (int)py;
@@ -1134,7 +1178,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         int total;
         if (compact) {
             const float Lh = 2.5f * histogramWidth;
-            const float inv_cos = 1.0f / cosT, inv_sin = 1.0f / sinT;      // (unused where the component is ~0)
+            const float inv_cos = in.inv_cos, inv_sin = in.inv_sin;        // (unused where the component is ~0)
             int run = 0;
             for (int c0 = 0; c0 < side; c0 += 64) {
                 const int cidx = c0 + lane;
@@ -1322,6 +1366,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                 }
             }
         };
+#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 2             // tools: a descriptor's prologue and epilogue alone (no sample is visited)
+        if (total < 0)
+#endif
         if (interior) walk(std::true_type{}); else walk(std::false_type{});
 #if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1
         if (abl_acc == 0x123456789abcdefull) atomicAdd(patch, abl_acc);

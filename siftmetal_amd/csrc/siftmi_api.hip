@@ -926,8 +926,15 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
         hipLaunchKernelGGL((orientation_kernel<false, 4>), dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                            c->d_ori_angles);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(expand_descriptors_kernel, dim3(groups), dim3(1024), 0, st, P, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
-                       c->d_desc_in, cnt(c, C_DESC), cnt(c, C_ORIENTED));
+    if (coop) {
+        hipLaunchKernelGGL(expand_descriptors_kernel<true>, dim3(groups), dim3(1024), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
+                           c->d_desc_in, cnt(c, C_DESC), cnt(c, C_ORIENTED));
+    } else {
+        hipLaunchKernelGGL(expand_descriptors_kernel<false>, dim3(groups), dim3(1024), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count, c->d_ori_angles,
+                           c->d_desc_in, cnt(c, C_DESC), cnt(c, C_ORIENTED));
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(desc_derive_kernel, dim3(64, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_DESC), c->d_desc_in);
+    }
     HIP_TRY(hipGetLastError());
     t_end(c);
     t_begin(c, SIFTMI_T_DESCRIBE);

@@ -1,5 +1,6 @@
 """Stage times of one 64 x 1080p step on dense natural texture (bench.py's config.dense) or on the benchmark frames, per-launch
 hipEvents (serialised launches: no overlap between octave chains).
+The line ends with a digest of the packed keypoint + descriptor records: equal digests from two builds = byte-identical results.
 usage: [SIFTMI_LIB=<experiment build>] python tools/dense_stage_times.py [steps] [dense|bench]"""
 import os
 import sys
@@ -25,4 +26,8 @@ for _ in range(steps):
 fs.synchronize()
 tm = eng.timings()
 r = fs.results_host()
-print(os.environ.get("SIFTMI_LIB", "libsiftmi.so"), {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0}, r["n_keypoints"], r["n_descriptors"], flush=True)
+import hashlib
+import numpy as np
+digest = hashlib.sha256(np.ascontiguousarray(r["keypoints"]).tobytes() + np.ascontiguousarray(r["descriptors"]).tobytes()).hexdigest()[:16]
+print(os.environ.get("SIFTMI_LIB", "libsiftmi.so"), {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0}, r["n_keypoints"], r["n_descriptors"],
+      "sha256 of the packed records", digest, flush=True)
