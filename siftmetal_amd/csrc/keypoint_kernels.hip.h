@@ -852,8 +852,11 @@ __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, 
 // than wavefront slots and a window of ~850 samples is 13 dependent rounds for one wavefront, 4 for a workgroup.  Same samples
 // into the same u64 fixed-point bins: bit-identical.
 // WPB: wavefronts per workgroup (COOP = false), see descriptor_kernel
+#ifndef SIFTMI_ORI_WAVES
+#define SIFTMI_ORI_WAVES 7
+#endif
 template <bool COOP, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) void orientation_kernel(PyramidDesc P, DetectParams prm,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI_ORI_WAVES))) void orientation_kernel(PyramidDesc P, DetectParams prm,
                                                          const KeypointRec *__restrict__ kps, const int32_t *__restrict__ kp_count,
                                                          int32_t *__restrict__ ori_count, float *__restrict__ ori_angles) {
     // 4 private copies of the 36-bin histogram per wave (copy = lane % 4), 37 u64 apart so that the copies of a bin sit on
@@ -1099,10 +1102,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // done, and descriptors differ 4x in their sample count, so with four independent wavefronts per workgroup a quarter of the slots
 // idles at workgroup tails on dense frames (4.35 of 6 resident, PMC round 4)
 #ifndef SIFTMI_DESC_WAVES
-#define SIFTMI_DESC_WAVES 7                                // wavefronts per SIMD the descriptor kernel's register budget is sized for (72 VGPRs)
+#define SIFTMI_DESC_WAVES 7                                // wavefronts per SIMD the descriptor kernel's register budget is sized for (72 VGPRs);
+                                                           // the one-wavefront form of large launches: one more (64 VGPRs, 16 B of scratch outside the
+                                                           // loop, 4.9 KB of LDS per wavefront): 5.52-5.55 against 5.56-5.72 ms on dense frames
 #endif
 template <bool COOP, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI_DESC_WAVES))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI_DESC_WAVES + (WPB == 1 ? 1 : 0)))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
                                                         float *__restrict__ desc_f32 /* may be null */) {
@@ -1117,7 +1122,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
     constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
     static_assert(WPB == 4 || (!COOP && WPB == 1), "COOP shares one descriptor among the four wavefronts of a workgroup");
     __shared__ unsigned long long patch_all[WPB][NCOPY * DESC_N];
-    __shared__ int col_start_all[WPB][MAXCOL + 1];
+    __shared__ short col_start_all[WPB][MAXCOL + 2];          // walk index of a row's first candidate (<= 128 * 128 / 1: fits 15 bits)
     __shared__ short col_lo_all[WPB][MAXCOL];
     __shared__ short col_len_all[WPB][MAXCOL];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1126,7 +1131,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
     const int lidx = COOP ? (int)threadIdx.x : lane;
     unsigned long long *patch0 = patch_all[hw_];
     unsigned long long *patch = patch0 + (lane & (NCOPY - 1));           // this lane's copy; bin slot k sits at patch[k * NCOPY]
-    int *col_start = col_start_all[wv];
+    short *col_start = col_start_all[wv];
     short *col_lo = col_lo_all[wv];
     short *col_len = col_len_all[wv];
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
@@ -1206,11 +1211,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                 int incl = nun;                                            // inclusive wave prefix sum
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-                if (cidx < side) { col_start[cidx] = run + incl - nun; col_lo[cidx] = (short)lo; col_len[cidx] = (short)len; }
+                if (cidx < side) { col_start[cidx] = (short)(run + incl - nun); col_lo[cidx] = (short)lo; col_len[cidx] = (short)len; }
                 run += __shfl(incl, 63);
             }
             total = run;
-            if (lane == 0) col_start[side] = total;
+            if (lane == 0) col_start[side] = (short)total;
         } else {
             total = side * side;
         }
