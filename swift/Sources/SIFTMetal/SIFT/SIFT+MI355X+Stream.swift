@@ -63,36 +63,66 @@ public final class SIFTStream {
 
     // MARK: exchange between the GPUs of a node (one process per GPU, RCCL over xGMI)
 
+    /// A collective that cannot complete: a rank died or hangs (every host wait of the exchange is bounded:
+    /// `SIFTMI_EXCHANGE_TIMEOUT_S`, `setExchangeTimeout`), the communicator reported an error, or the call was out of order.
+    /// After a time-out the communicator is aborted and every later exchange call throws the same message; results of the
+    /// local stream (`result(back:octaves:)`) stay available.
+    public struct ExchangeError: Error, CustomStringConvertible {
+        public let code: Int32
+        public let description: String
+    }
+
+    private func check(_ rc: Int32) throws {
+        if rc != SIFTMI_OK.rawValue { throw ExchangeError(code: rc, description: String(cString: siftmi_last_error())) }
+    }
+
     /// Rank 0 creates the id and hands it to the other ranks out of band.
-    public static func makeExchangeID() -> [UInt8] {
+    public static func makeExchangeID() throws -> [UInt8] {
         var id = [UInt8](repeating: 0, count: Int(SIFTMI_UNIQUE_ID_BYTES))
-        precondition(siftmi_exchange_unique_id(&id) == SIFTMI_OK.rawValue, String(cString: siftmi_last_error()))
+        let rc = siftmi_exchange_unique_id(&id)
+        if rc != SIFTMI_OK.rawValue { throw ExchangeError(code: rc, description: String(cString: siftmi_last_error())) }
         return id
     }
 
-    /// Collective over all `world` ranks.
-    public func joinExchange(id: [UInt8], rank: Int, world: Int) {
-        let rc = siftmi_exchange_create(stream, id, Int32(rank), Int32(world), &exchange)
-        precondition(rc == SIFTMI_OK.rawValue, String(cString: siftmi_last_error()))
+    /// Collective over all `world` ranks.  Throws when the communicator does not report `world` ranks and this rank number.
+    public func joinExchange(id: [UInt8], rank: Int, world: Int) throws {
+        try check(siftmi_exchange_create(stream, id, Int32(rank), Int32(world), &exchange))
+    }
+
+    /// (ranks, rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank).
+    public func exchangeRanks() throws -> (ranks: Int, rank: Int) {
+        var n: Int32 = 0, r: Int32 = -1
+        try check(siftmi_exchange_ranks(exchange, &n, &r))
+        return (Int(n), Int(r))
+    }
+
+    /// Deadline of every host wait of the exchange, in seconds (default 120, or `SIFTMI_EXCHANGE_TIMEOUT_S`).
+    public func setExchangeTimeout(seconds: Double) throws {
+        try check(siftmi_exchange_set_timeout(exchange, seconds))
     }
 
     /// Collective: all-gather the last submitted step's keypoints and descriptors (asynchronous, side stream).
-    public func gather() {
-        precondition(siftmi_exchange_gather(exchange, 0) == SIFTMI_OK.rawValue, String(cString: siftmi_last_error()))
+    public func gather() throws {
+        try check(siftmi_exchange_gather(exchange, 0))
+    }
+
+    /// Bounded wait for every gather enqueued so far (before a process-wide barrier or a device synchronisation,
+    /// which would otherwise wait for ever on a collective a dead rank never joins).
+    public func waitForExchange() throws {
+        try check(siftmi_exchange_wait(exchange))
     }
 
     /// Device view of every rank's results of the gather `back` gathers ago; `complete == 0` until the next
     /// `gather()` / `finishExchange()` when some rank held more records than were sent.
-    public func gathered(back: Int = 0, wait: Bool = true) -> siftmi_gathered {
+    public func gathered(back: Int = 0, wait: Bool = true) throws -> siftmi_gathered {
         var g = siftmi_gathered()
         let none = UnsafeMutableRawPointer(bitPattern: -1)              // SIFTMI_NO_STREAM
-        let rc = siftmi_exchange_result(exchange, Int32(back), &g, none, wait ? 1 : 0)
-        precondition(rc == SIFTMI_OK.rawValue, String(cString: siftmi_last_error()))
+        try check(siftmi_exchange_result(exchange, Int32(back), &g, none, wait ? 1 : 0))
         return g
     }
 
     /// Collective, end of stream.
-    public func finishExchange() {
-        precondition(siftmi_exchange_finish(exchange, nil, nil) == SIFTMI_OK.rawValue, String(cString: siftmi_last_error()))
+    public func finishExchange() throws {
+        try check(siftmi_exchange_finish(exchange, nil, nil))
     }
 }
