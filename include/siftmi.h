@@ -98,7 +98,10 @@ typedef struct siftmi_config {
                                            octave (octave k's scan and keypoint stages beside octave k+1's pyramid): 0 = default (on,
                                            unless a frame's first octave exceeds 48 Mpixel), 1 = always, -1 = never (every kernel
                                            alone on the GPU: what a per-kernel profile wants) */
-    int32_t reserved[2];
+    int32_t descriptor_patch_lds;       /* 1 = the descriptor kernel of large launches stages every 16 x 16-sample tile of a window (18 x 18
+                                           texels) in LDS and samples from there instead of reading the layer through the caches; the
+                                           descriptors are byte-identical, the stage is slower (profiles/desc_patch_lds_r05.log): 0 = default */
+    int32_t reserved[1];
 } siftmi_config;
 
 /* Replaces SIFTExtremaResult (Sources/MetalShaders/include/SIFTExtrema.h:14-18). */

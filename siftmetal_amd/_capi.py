@@ -41,7 +41,7 @@ class Config(C.Structure):
                 ("descriptor_scales_per_octave", C.c_int32), ("full_neighbourhood", C.c_int32),
                 ("max_batch", C.c_int32), ("max_extrema", C.c_int32), ("max_keypoints", C.c_int32),
                 ("max_descriptors", C.c_int32), ("keep_descriptor_floats", C.c_int32), ("use_hip_graph", C.c_int32), ("count_raw_extrema", C.c_int32),
-                ("blur_march_min_blocks", C.c_int32), ("blur_chain_max_tiles", C.c_int32), ("graph_fork", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("blur_march_min_blocks", C.c_int32), ("blur_chain_max_tiles", C.c_int32), ("graph_fork", C.c_int32), ("descriptor_patch_lds", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Stats(C.Structure):

@@ -1106,7 +1106,14 @@ __device__ __forceinline__ float wave_sum(float v) {
                                                            // the one-wavefront form of large launches: one more (64 VGPRs, 16 B of scratch outside the
                                                            // loop, 4.9 KB of LDS per wavefront): 5.52-5.55 against 5.56-5.72 ms on dense frames
 #endif
-template <bool COOP, int WPB = 4>
+// PATCH (siftmi_config.descriptor_patch_lds; BASELINE north_star: "LDS tile staging for ... 16x16 descriptor patches"): an interior window
+// is walked in 16 x 16-sample tiles of its bounding box; a tile's 18 x 18 texels (the samples and their +-1 neighbours) are copied into
+// LDS once and every lane takes the four samples of one quarter row from there.  Same samples, same arithmetic, order-free bins:
+// byte-identical descriptors (tests/test_gpu_parity.py::test_descriptor_patch_staging_is_byte_identical).  It is NOT the default: a
+// window's texels are used ~4 times each and the L1 / L2 already serve that (profiles/pmc_descriptor_dense_r05.txt: 0.9 MB fetched from HBM
+// by 2 M workgroups), while tiles of the bounding box visit the corners the compacted row walk skips and every 256 samples wait for a
+// load -> LDS -> read round trip: 13.4 against 5.5 ms per 1.13 M descriptors on dense frames (profiles/desc_patch_lds_r05.log).
+template <bool COOP, int WPB = 4, bool PATCH = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI_DESC_WAVES + (WPB == 1 ? 1 : 0)))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
@@ -1125,6 +1132,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
     __shared__ short col_start_all[WPB][MAXCOL + 2];          // walk index of a row's first candidate (<= 128 * 128 / 1: fits 15 bits)
     __shared__ short col_lo_all[WPB][MAXCOL];
     __shared__ short col_len_all[WPB][MAXCOL];
+    constexpr int TP = 20;                                 // floats per staged tile row (18 used; 80 B keeps a quad's row segment 16-byte aligned)
+    static_assert(!PATCH || !COOP, "PATCH: one wavefront per descriptor");
+    __shared__ __attribute__((aligned(16))) float tile_all[PATCH ? WPB : 1][PATCH ? 18 * TP : 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hw_ = COOP ? 0 : wv;                          // whose histogram copies: the workgroup's (COOP) or this wave's
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
@@ -1287,6 +1297,50 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         };
         auto walk = [&](auto interior_tag) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
+            if constexpr (PATCH && INTERIOR) if (compact) {   // (every lane takes part: wave-level loops)
+                float *tile = tile_all[wv];
+                const int nt = (side + 15) >> 4;                        // tiles per side of the bounding box [-radius, radius]^2
+                for (int ty = 0; ty < nt; ty++) {
+                    // the columns the 16 window rows of this tile row can use (wave-uniform; lanes 16 ... 63 repeat lanes 0 ... 15)
+                    const int trow = ty * 16 + (lane & 15);
+                    int lo_t = 30000, hi_t = -30000;
+                    if (trow < side && col_len[trow] > 0) { lo_t = col_lo[trow]; hi_t = lo_t + col_len[trow] - 1; }
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) { lo_t = min(lo_t, __shfl_xor(lo_t, off)); hi_t = max(hi_t, __shfl_xor(hi_t, off)); }
+                    lo_t = __builtin_amdgcn_readfirstlane(lo_t); hi_t = __builtin_amdgcn_readfirstlane(hi_t);
+                    if (hi_t < lo_t) continue;
+                    const int i0 = ty * 16 - radius;                    // window row (y offset) of the tile's first sample row
+                    for (int tx = (lo_t + radius) >> 4; tx <= (hi_t + radius) >> 4; tx++) {
+                        const int j0 = tx * 16 - radius;                // x offset of the tile's first sample column
+                        // stage texels (ipx + j0 - 1 + c, ipy + i0 - 1 + r), r, c in [0, 18): the samples and their +-1 neighbours.  A tile
+                        // may reach past the window (the bounding box is rounded up to 16): such texels come from the next image row, or
+                        // read 0 past the layer's end (range-checked buffer), and belong to samples outside every row interval.
+                        __builtin_amdgcn_wave_barrier();                // the previous tile's reads are done (one wavefront: LDS in order)
+                        for (int k = lane; k < 18 * 18; k += 64) {
+                            const int r = k / 18, cc = k - r * 18;
+                            tile[r * TP + cc] = layer_ld(g, __mul24(ipy + i0 - 1 + r, g.pitch) + ((ipx + j0 - 1 + cc) << 2));
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        __threadfence_block();
+                        const int r = lane >> 2, q4 = (lane & 3) << 2;  // this lane: sample row r of the tile, columns q4 ... q4 + 3
+                        const int srow = ty * 16 + r;
+                        int lo = 0, len = 0;
+                        if (srow < side) { lo = col_lo[srow]; len = col_len[srow]; }
+                        const float *tc = tile + (r + 1) * TP + q4;     // texel x - 1 of the quad's first sample, its own row
+                        float A[6], U[4], D[4];
+#pragma unroll
+                        for (int e = 0; e < 6; e++) A[e] = tc[e];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { U[e] = tc[e + 1 - TP]; D[e] = tc[e + 1 + TP]; }
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) {
+                            const int j = j0 + q4 + s4;
+                            sample(interior_tag, (j >= lo && j < lo + len) ? j : 30000, i0 + r, A[s4 + 2], A[s4], D[s4], U[s4]);
+                        }
+                    }
+                }
+                return;
+            }
             int cur = 0;                                                   // window row of this lane's current sample
             if (compact && lidx < total) {                                 // binary search once, then only advance
                 int lo_c = 0, hi_c = side - 1;                             // last row whose start <= lidx

@@ -319,6 +319,7 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     if (cfg->nspo < 1 || cfg->nspo + 3 > MAX_NG) return set_error(SIFTMI_E_BADARG, "nspo %d out of range [1, %d]", cfg->nspo, MAX_NG - 3);
     if (cfg->delta_min != 0.5f) return set_error(SIFTMI_E_BADARG, "delta_min must be 0.5 (2x seed image)");
     if (cfg->max_batch < 1 || cfg->max_batch > 4096) return set_error(SIFTMI_E_BADARG, "max_batch %d out of range", cfg->max_batch);
+    if (cfg->descriptor_patch_lds != 0 && cfg->descriptor_patch_lds != 1) return set_error(SIFTMI_E_BADARG, "descriptor_patch_lds must be 0 or 1");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return set_error(SIFTMI_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -943,7 +944,10 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
         hipLaunchKernelGGL((descriptor_kernel<true, 4>), dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                            c->d_desc_f32);
     else {
-        if (wpb_desc == 1)
+        if (wpb_desc == 1 && c->cfg.descriptor_patch_lds)
+            hipLaunchKernelGGL((descriptor_kernel<false, 1, true>), dim3(wg1, groups), dim3(64), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC),
+                               c->d_desc, c->d_desc_f32);
+        else if (wpb_desc == 1)
             hipLaunchKernelGGL((descriptor_kernel<false, 1>), dim3(wg1, groups), dim3(64), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                                c->d_desc_f32);
         else

@@ -576,6 +576,32 @@ def test_dense_natural_texture_1080p_vs_oracle(sm, butterfly_bgra):
     assert match >= 0.995 * tot, (match, tot)
 
 
+def test_descriptor_patch_staging_is_byte_identical(sm, butterfly_bgra):
+    """BASELINE north_star names "LDS tile staging for ... 16x16 descriptor patches".  The descriptor kernel has that form as a
+    configuration (siftmi_config.descriptor_patch_lds: every 16 x 16-sample tile of a window's bounding box, 18 x 18 texels, copied to
+    LDS and sampled from there); it is not the default because it is slower.  Same samples, same arithmetic,
+    order-free bins: the packed records and the pre-quantisation floats must equal the default kernel's byte for byte -- on dense
+    natural texture (windows of every size and rotation, border windows taking the non-staged path) and on the blob field."""
+    from tests.synth import blob_frame
+    nat = _natural_1080p(butterfly_bgra)
+    frames = np.stack([nat, np.ascontiguousarray(nat[::-1]), np.ascontiguousarray(nat[:, ::-1]),
+                       np.ascontiguousarray(blob_frame(1920, 1080, 3, gray=False))])          # 4 x 1080p: the one-wavefront (large-launch) kernels
+    out = []
+    for flag in (0, 1):
+        eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=4, keep_descriptor_floats=1, descriptor_patch_lds=flag)
+        k, kc, d, dc = eng.detect_describe_batch(frames)
+        fl = [eng.descriptor_floats(o, frame=f).copy() for f in range(4) for o in range(4)]
+        out.append((k.copy(), kc.copy(), d.copy(), dc.copy(), fl))
+        eng.close()
+    (k0, kc0, d0, dc0, f0), (k1, kc1, d1, dc1, f1) = out
+    assert int(dc0.sum()) > 40000                                     # dense content: tens of thousands of windows
+    assert np.array_equal(kc0, kc1) and np.array_equal(dc0, dc1)
+    assert k0.tobytes() == k1.tobytes() and d0.tobytes() == d1.tobytes()
+    assert all(np.array_equal(a, b) for a, b in zip(f0, f1))
+    with pytest.raises(sm.SiftmiError):
+        sm.Engine(64, 64, n_octaves=1, descriptor_patch_lds=2)
+
+
 def test_heavy_noise_never_overruns(sm):
     """Unstructured input (white noise) and a deliberately tiny candidate capacity.  Either everything
     fits, or the call reports SIFTMI_E_CAPACITY with truncated-but-valid results -- never a crash."""
