@@ -683,6 +683,30 @@ def main():
             dev_sync()
             out["config"]["dense"]["stage_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in eng.timings().items()}
             eng.enable_timings(False)
+            # the north-star's "LDS tile staging for 16x16 descriptor patches" is a configuration of the descriptor kernel, not its default:
+            # the same dense step with it on, so that every round's line says what the choice costs (identical record counts checked)
+            e_p = sm.Engine(W, H, device=local_rank, n_octaves=N_OCT, nspo=NSPO, max_batch=min(args.batch, F), descriptor_patch_lds=1, **tune)
+            r_p = smstream.FrameStream(e_p, F, device=dev)
+            for _ in range(2):
+                r_p.run(d_dense)
+            dev_sync()
+            e_p.enable_timings(True)
+            e_p.reset_timings()
+            n_p = max(2, args.steps // 4)
+            for _ in range(n_p):
+                r_p.run(d_dense)
+            dev_sync()
+            pres = r_p.results_host()
+            if (pres["n_keypoints"], pres["n_descriptors"]) != (dres["n_keypoints"], dres["n_descriptors"]):
+                raise SystemExit("bench: descriptor_patch_lds results differ")
+            out["config"]["dense"]["descriptor_patch_lds"] = {
+                "what": "siftmi_config.descriptor_patch_lds = 1: 18x18-texel tiles of every descriptor window staged in LDS (byte-identical records: tests)",
+                "describe_ms_per_step": round(e_p.timings()["describe"][0] / n_p, 4),
+                "describe_ms_per_step_default": out["config"]["dense"]["stage_ms_per_step"]["describe"]}
+            log("dense step, descriptor stage with LDS-staged patches: %.3f ms (default %.3f)" %
+                (out["config"]["dense"]["descriptor_patch_lds"]["describe_ms_per_step"], out["config"]["dense"]["stage_ms_per_step"]["describe"]))
+            r_p.close()
+            e_p.close()
         dev_sync()
         d_dense.close()
     if rank == 0 and not args.no_cpu and world == 1:
