@@ -1371,8 +1371,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                     // quads: row y holds texels x - 1 ... x + 4 of the quad's four samples x ... x + 3 (b128 + b64), rows y - 1 and y + 1
                     // texels x ... x + 3 (b128 each).  A partial last quad reads up to three texels past its row's interval -- inside the
                     // image row, the next row, or past the layer's end where the range-checked buffer returns 0 -- and never uses them.
-                    // No software pipelining here: a trip is ~420 vector instructions, the other six wavefronts of the SIMD cover its
-                    // one memory latency, and the 14 registers a prefetched quad would hold are the seventh wavefront (measured equal
+                    // No software pipelining here: a trip is ~400 vector instructions, the other wavefronts of the SIMD (7 in the one-wavefront form) cover its
+                    // one memory latency, and the 14 registers a prefetched quad would hold cost a resident wavefront (measured equal
                     // or 1-2 % behind with the prefetch, profiles/desc_variants_r05.log).
                     auto locate_q = [&](int q, int &j0, int &i, int &nv) {
                         while (q >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }
