@@ -592,6 +592,9 @@ def test_descriptor_patch_staging_is_byte_identical(sm, butterfly_bgra):
         k, kc, d, dc = eng.detect_describe_batch(frames)
         fl = [eng.descriptor_floats(o, frame=f).copy() for f in range(4) for o in range(4)]
         out.append((k.copy(), kc.copy(), d.copy(), dc.copy(), fl))
+        for _ in range(2):                                            # the captured launch sequence (second sighting) and its replay
+            k2, kc2, d2, dc2 = eng.detect_describe_batch(frames)
+            assert k2.tobytes() == k.tobytes() and d2.tobytes() == d.tobytes()
         eng.close()
     (k0, kc0, d0, dc0, f0), (k1, kc1, d1, dc1, f1) = out
     assert int(dc0.sum()) > 40000                                     # dense content: tens of thousands of windows
