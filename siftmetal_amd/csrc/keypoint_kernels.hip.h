@@ -964,13 +964,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                     for (int s4 = 0; s4 < 4; s4++) {
                         const float u = (float)(i0 + s4) * inv_sigma;
                         const float wgt = s4 < nv ? __builtin_amdgcn_exp2f(fmaf(u, u, vv) * k_exp) : 0.0f;
-                        const float tx = (A[s4 + 2] - A[s4]) * 0.5f, ty = (D[s4] - U[s4]) * 0.5f;
-                        const float orientation = atan2_lean(tx, ty);
-                        const float magnitude = __builtin_amdgcn_sqrtf(fmaf(tx, tx, ty * ty));
+                        // the gradient is (dx, dy) / 2 (SIFTGradient.metal:31-32): halving is exact, so the angle is that of (dx, dy) (the
+                        // octant quotient's mantissa does not see a common power of two) and |gradient| = sqrt(dx^2 + dy^2) / 2 with the 1/2
+                        // folded into the fixed-point scale -- two multiplies less per sample, the same bits.  |angle| <= pi puts the bin
+                        // in [-18, 18]: one wrap.
+                        const float dx = A[s4 + 2] - A[s4], dy = D[s4] - U[s4];
+                        const float orientation = atan2_lean(dx, dy);
+                        const float magnitude2 = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
                         int bin = (int)roundf(orientation * (float)(ORI_BINS / (2.0 * 3.14159265358979323846)));
                         if (bin < 0) bin += ORI_BINS;
-                        if (bin >= ORI_BINS) bin -= ORI_BINS;
-                        atomicAdd(&hist[bin], fix32_product(wgt * magnitude, 4294967296.0f));
+                        atomicAdd(&hist[bin], fix32_product(wgt * magnitude2, 2147483648.0f));
                     }
                 }
             } else {
