@@ -937,6 +937,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                 const float m = wgt * magnitude;
                 atomicAdd(&hist[bin], fix32_product(m, 4294967296.0f));
             };
+#if defined(SIFTMI_ORI_ABL) && SIFTMI_ORI_ABL == 2               // tools: a keypoint's prologue and tail alone (no sample is visited)
+            if (total < 0)
+#endif
             if (interior) {
                 // Round 5: an interior window is walked in QUADS, as the descriptor's: four consecutive samples of a window row per lane
                 // and trip (the last quad of a row runs up to three columns past the window: those samples get weight 0).  The index
