@@ -92,6 +92,13 @@ static void bench_R(Ctx &c, float rho) {
             const char *nm[8] = {"issue", "H", "B2wait", "V", "stores", "B3wait", "vmwait+ldsw", "B1wait"}; \
             printf("      stamps (cycles per wave-step, share):"); for (int k = 0; k < 8; k++) printf(" %s %.0f (%.0f%%)", nm[k], sum[k] / ((double)tx * c.nf * ((c.h + S_ - 1) / S_) * 4) , 100.0 * sum[k] / tot); printf("\n"); } }
     VR(32, 128, 4, 0) VR(32, 256, 4, 0) VR(32, 256, 4, 24)
+    // round 5: 16-row steps, two wavefronts per workgroup (18 KB ring: eight workgroups per CU, cheaper barriers); R <= 8 only (ring = 2 S rows)
+#define VRS(S_, CHR_, MINW_, DBG_) if constexpr (2 * R <= S_) { using G = RingGeom<R <= S_ / 2 ? R : 1, S_>; \
+        const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
+        const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
+        Activity dbg{(unsigned char *)c.diag, 0, 0, 0.0f}; \
+        run_variant("ring S=" #S_ " (" "2 wavefronts) rows/chunk=" #CHR_ " minw=" #MINW_ " dbg=" #DBG_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<(R <= S_ / 2 ? R : 1), MINW_, S_, false, false, DBG_>), grid, dim3(8 * S_), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, dbg, none); }); }
+    VRS(16, 256, 4, 0) VRS(16, 512, 4, 0) VRS(16, 256, 4, 24)
 #define VRH4(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
