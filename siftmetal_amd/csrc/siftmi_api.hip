@@ -1075,7 +1075,8 @@ static int replay_or_capture(siftmi_ctx *c, hipStream_t st, const siftmi_ctx::Gr
     key.fork = fork_chains(c);                               // (may change between calls: the stream's density hint)
     key.dense = c->dense_hint;
     *launched = false;
-    const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && getenv("SIFTMI_NO_GRAPH") == nullptr;
+    static const bool graphs_off = getenv("SIFTMI_NO_GRAPH") != nullptr;    // (read once: no environment scan per call)
+    const bool want_graph = c->cfg.use_hip_graph && !c->timing && !c->graph_failed && !graphs_off;
     if (!want_graph) return SIFTMI_OK;
     int rc = SIFTMI_OK;
     hipGraphExec_t exec = nullptr;
