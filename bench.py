@@ -136,19 +136,16 @@ def make_dense_frames(n):
     return np.stack([np.roll(full, 16 * (i % 8), axis=1) for i in range(n)])
 
 
-def cpu_baseline(frames, seconds_budget=18.0, threads_per_frame=None):
+def cpu_baseline(frames, seconds_budget=18.0):
     """Times the oracle (oracle/sift_oracle.c: a literal restatement of the reference's algorithm, not a tuned CPU SIFT) on a
     bounded sample of the same frames.  One oracle call spreads a frame's stages over OpenMP threads and scales poorly (4.2x on
     128 cores: its serial stretches and its per-tap index arithmetic); frames are independent, so the all-cores figure runs
-    whole frames in parallel -- one thread each when the host has at least as many threads as frames, else 8 threads each -- the
-    way a CPU deployment of the reference's algorithm would.  Then one thread alone."""
+    several frames at a time, 8 threads each -- the way a CPU deployment of the reference's algorithm would.  Then one thread."""
     import threading
     from oracle import pyoracle
     cores = pyoracle.num_threads()
-    # threads per frame: the oracle's own OpenMP scaling is poor (per-tap index arithmetic, serial stretches), whole frames in parallel
-    # do better -- measured on a 256-thread host: 3.7 / 3.9 / 5.9 / 7.0 Mpixel/s at 8 / 4 / 2 / 1 threads per frame
-    per = threads_per_frame if threads_per_frame else (1 if cores >= len(frames) else 8 if cores >= 16 else max(1, cores))
-    workers = max(1, min(cores // per, len(frames)))
+    per = 8 if cores >= 16 else max(1, cores)
+    workers = max(1, cores // per)
     done_by, desc_by = [0] * workers, [0] * workers
     t0 = time.time()
 
