@@ -735,6 +735,12 @@ __device__ __forceinline__ unsigned long long fix32_product(float p, float v32) 
     return (unsigned long long)r;
 }
 __device__ __forceinline__ float from_fix32(unsigned long long v) { return (float)v * 2.3283064365386963e-10f; }
+// Round 6: the sample loops add the BITS of a denormal-range float (descriptor_kernel's header) to u32 bins
+typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+__device__ __forceinline__ void lds_add_bits(unsigned byte_addr, int u32_offset, float contribution) {
+    lds_u32_t *p = (lds_u32_t *)(size_t)byte_addr;
+    __hip_atomic_fetch_add(p + u32_offset, __float_as_uint(contribution), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // atan2(y, x) of finite arguments for the sample loops (their VALU count is the limit of the orientation and descriptor
 // kernels; the library atan2f is 38 of it, with exponent juggling for a correctly scaled quotient and inf / nan cases that
@@ -777,18 +783,36 @@ __device__ __forceinline__ float octant_bin(float y, float x) {
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
     const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
     const float s = t * t;
-    float q = 3.338654274e-03f;                           // atan2_lean's coefficients x 4 / pi (tools/fit_atan.py)
-    q = fmaf(q, s, -1.926696758e-02f);
-    q = fmaf(q, s, 5.235734632e-02f);
-    q = fmaf(q, s, -9.379525972e-02f);
-    q = fmaf(q, s, 1.346312058e-01f);
-    q = fmaf(q, s, -1.806213739e-01f);
-    q = fmaf(q, s, 2.545256334e-01f);
-    q = fmaf(q, s, -4.244087546e-01f);
+    // Round 6: six coefficients instead of eight (tools/fit_atan.py 6, x 4 / pi): 8.8e-7 of a bin worst case (6.2e-7 rad; the eight-term
+    // fit reached the float floor, 2.9e-7 rad).  A bin error e moves e of a sample's weight to the neighbouring orientation bin; the
+    // descriptor's stated tolerance is 1e-4 (L2 of the unit vector), the measured effect is in profiles/desc_margin_r06.log.
+    float q = 9.388612583e-03f;
+    q = fmaf(q, s, -4.522449896e-02f);
+    q = fmaf(q, s, 1.046182811e-01f);
+    q = fmaf(q, s, -1.705982834e-01f);
+    q = fmaf(q, s, 2.528888583e-01f);
+    q = fmaf(q, s, -4.243120849e-01f);
     float r = t * fmaf(s, q, 1.27323954473516268f);        // 4 / pi atan(t), in [0, 1]
     r = ay > ax ? 2.0f - r : r;
     r = x < 0.0f ? 4.0f - r : r;
     return y < 0.0f ? 8.0f - r : r;
+}
+// The same in units of 10 degrees (the 36 bins of the orientation histogram), in [0, 36]: coefficients x 18 / pi.
+__device__ __forceinline__ float octant_bin36(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
+    const float s = t * t;
+    float q = 4.224875569e-02f;
+    q = fmaf(q, s, -2.035102397e-01f);
+    q = fmaf(q, s, 4.707822502e-01f);
+    q = fmaf(q, s, -7.676922679e-01f);
+    q = fmaf(q, s, 1.137999892e+00f);
+    q = fmaf(q, s, -1.909404397e+00f);
+    float r = t * fmaf(s, q, 5.72957795130823209f);        // 18 / pi atan(t), in [0, 4.5]
+    r = ay > ax ? 9.0f - r : r;
+    r = x < 0.0f ? 18.0f - r : r;
+    return y < 0.0f ? 36.0f - r : r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,12 +870,16 @@ __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, 
 // ------------------------------------------------------------------------------------------------
 // Orientation: SIFTOctave.getKeypointOrientations (SIFTOctave.swift:290-382) + SIFTOrientation.metal.
 // One wavefront per keypoint; the (2r+1)^2 window is strided over the 64 lanes into a 36-bin LDS
-// histogram (u64 fixed point, see fix32_product); smoothing / peak search run on lanes 0..35 with shuffles.
+// histogram (integer sums, see descriptor_kernel's header); smoothing / peak search run on lanes 0..35 with shuffles.
 // ori_count[k] = -1 when the host-side border filter of the reference rejects the keypoint.
 // COOP (as descriptor_kernel): the four wavefronts of a workgroup share one keypoint -- on a frame or two there are fewer keypoints
 // than wavefront slots and a window of ~850 samples is 13 dependent rounds for one wavefront, 4 for a workgroup.  Same samples
-// into the same u64 fixed-point bins: bit-identical.
+// into the same integer bins: bit-identical.
 // WPB: wavefronts per workgroup (COOP = false), see descriptor_kernel
+// Round 6 (as the descriptor's sample loop; costs in profiles/ubench_mix_r06.log): contributions are denormal floats whose bits go to a u32
+// LDS add (24 fractional bits); the Gaussian weight exp(-(i^2 + j^2) / 2 lambda^2 sigma^2) is the product of two entries of a per-keypoint
+// table (zero past the window: the padding of a row's last quad needs no mask); the bin is formed directly in units of 10 degrees in
+// [0, 36] (octant_bin36: no scaling, no wrap of a negative angle) and rounded by one conversion, slot 36 being bin 0 again.
 #ifndef SIFTMI_ORI_WAVES
 #define SIFTMI_ORI_WAVES 7
 #endif
@@ -859,15 +887,17 @@ template <bool COOP, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI_ORI_WAVES))) void orientation_kernel(PyramidDesc P, DetectParams prm,
                                                          const KeypointRec *__restrict__ kps, const int32_t *__restrict__ kp_count,
                                                          int32_t *__restrict__ ori_count, float *__restrict__ ori_angles) {
-    // 4 private copies of the 36-bin histogram per wave (copy = lane % 4), 37 u64 apart so that the copies of a bin sit on
-    // different LDS banks: neighbouring lanes (neighbouring pixels) mostly share a bin, and same-address lanes of one
-    // ds_add_u64 serialise
+    // 4 private copies of the histogram per wave (copy = lane % 4), 37 slots apart so that the copies of a bin sit on different LDS
+    // banks: neighbouring lanes (neighbouring pixels) mostly share a bin, and same-address lanes of one LDS add serialise.  Slot 36 = bin 0.
     constexpr int OCOPY = SIFTMI_ORI_NCOPY, OSTRIDE = ORI_BINS + 1;
+    constexpr int OTAB = 128;                               // window columns the weight table covers (+ 4 entries of padding)
     static_assert(WPB == 4 || (!COOP && WPB == 1), "COOP shares one keypoint among the four wavefronts of a workgroup");
-    __shared__ unsigned long long hist_all[WPB][OCOPY * OSTRIDE];
+    __shared__ unsigned hist_all[WPB][OCOPY * OSTRIDE];
+    __shared__ float otab_all[WPB][OTAB + 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long *hist0 = hist_all[COOP ? 0 : wv];
-    unsigned long long *hist = hist0 + (lane & (OCOPY - 1)) * OSTRIDE;
+    unsigned *hist0 = hist_all[COOP ? 0 : wv];
+    const unsigned hist_lds = (unsigned)(size_t)(lds_u32_t *)(hist0 + (lane & (OCOPY - 1)) * OSTRIDE);   // byte address of this lane's copy
+    float *otab = otab_all[wv];
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one keypoint's window
     const int lidx = COOP ? (int)threadIdx.x : lane;
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
@@ -895,8 +925,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         const int absoluteX = (int)kp.abs_x, absoluteY = (int)kp.abs_y;     // :333-334 Int32 truncation
         const LayerView g = layer_view(layer_ptr(P, frame, o, kp.scale), w, h);
         if (COOP) __syncthreads();                                      // wave 0 is done reading the previous keypoint's bins
-        for (int c = lidx; c < OCOPY * OSTRIDE; c += STRIDE) hist0[c] = 0ull;
-        if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        for (int c = lidx; c < OCOPY * OSTRIDE; c += STRIDE) hist0[c] = 0u;
+        int half_shift = 0;
         {   // SIFTOrientation.metal:87-136
             const int x = (int)roundf((float)absoluteX / delta);
             const int y = (int)roundf((float)absoluteY / delta);
@@ -909,87 +939,86 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
             const int r = (int)ceilf(3.0f * lambda * sigma);
             const int side = 2 * r + 1, total = side * side;
             const float inv_side = 1.0f / (float)side;                 // idx / side below: idx + 0.5 keeps the quotient >= 0.5 / side off every integer, far more than the float error at idx < 2^20
+            // weight of a sample = gauss(i) gauss(j), gauss(k) = exp2(k_exp (k / sigma)^2) 2^-63 2^-half_shift: the product carries 2^-126,
+            // which makes (|gradient| weight) a float whose bits are its value in units of 2^-24 (descriptor_kernel's header).  A bin's total
+            // is below sqrt(2) / 2 (sum of gauss)^2 <= 0.7072 (2.5067 lambda sigma + 1)^2: 149 with the reference's lambda = 1.5; half_shift
+            // scales the unit up when a larger lambda would take that past 2^8.
+            const float sg = fmaf(2.5066283f * lambda, sigma, 1.0f), bound = 0.70710678f * sg * sg;
+            while (ldexpf(bound, -2 * half_shift) >= 240.0f) half_shift++;   // (wave-uniform; no trip with the reference's parameters)
+            const float gscale = ldexpf(1.0f, -63 - half_shift);
+            auto gauss = [&](int kk) -> float { const float u = (float)kk * inv_sigma; return __builtin_amdgcn_exp2f((u * u) * k_exp) * gscale; };
+            const bool tabled = side <= OTAB;
+            if (tabled) for (int c = lane; c < side + 3; c += 64) otab[c] = c < side ? gauss(c - r) : 0.0f;    // (each wave its own copy)
+            if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
             // The host border filter works on the float position, the window is centred on the rounded truncated one (up to two
             // pixels lower at delta = 0.5): almost every window still has all its samples and their +-1 neighbours inside the
-            // image (wave-uniform test) and takes the gradient as four loads at one offset, without per-sample range tests.
+            // image (wave-uniform test) and takes the gradient as wide loads at one offset, without per-sample range tests.
             const bool interior = x - r >= 1 && x + r <= w - 2 && y - r >= 1 && y + r <= h - 2;
-            auto sample = [&](auto interior_tag, int idx) {
-                constexpr bool INTERIOR = decltype(interior_tag)::value;
-                const int jj = (int)(((float)idx + 0.5f) * inv_side), ii = idx - jj * side;
-                const int j = jj - r, i = ii - r;
-                const float u = (float)i * inv_sigma, v = (float)j * inv_sigma;
-                const float wgt = __builtin_amdgcn_exp2f(fmaf(u, u, v * v) * k_exp);
-                float orientation, magnitude;
-                if (INTERIOR) {
-                    const int c = __mul24(y + j - 1, g.pitch) + ((x + i - 1) << 2);      // texel (x + i - 1, y + j - 1)
-                    const float tx = (layer_ld_s(g, c + 8, g.pitch) - layer_ld_s(g, c, g.pitch)) * 0.5f;
-                    const float ty = (layer_ld_s(g, c + 4, 2 * g.pitch) - layer_ld(g, c + 4)) * 0.5f;
-                    orientation = atan2_lean(tx, ty);
-                    magnitude = __builtin_amdgcn_sqrtf(fmaf(tx, tx, ty * ty));
-                } else {
-                    gradient_at<true>(g, x + i, y + j, orientation, magnitude);
-                }
-                // t = orientation / 2 pi, bin = round(36 t) in the reference: one multiply here.  The product can round
-                // differently from the quotient's only within an ulp of a half-integer, where atan2_lean's own 2.4 ulp already decide.
-                int bin = (int)roundf(orientation * (float)(ORI_BINS / (2.0 * 3.14159265358979323846)));
-                if (bin < 0) bin += ORI_BINS;
-                if (bin >= ORI_BINS) bin -= ORI_BINS;
-                const float m = wgt * magnitude;
-                atomicAdd(&hist[bin], fix32_product(m, 4294967296.0f));
+            // one sample: central differences (dx, dy), not halved -- the gradient is (dx, dy) / 2 (SIFTGradient.metal:31-32): halving is
+            // exact, so the angle atan2(tx, ty) is that of (dx, dy), and |gradient| = sqrt(dx^2 + dy^2) / 2 with the 1/2 in the unit
+            auto accumulate = [&](float dx, float dy, float gi, float gj) {
+                const float bin = octant_bin36(dx, dy);                 // 36 atan2(tx, ty) / 2 pi taken into [0, 36]
+                int b;
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(b) : "v"(bin));    // floor(bin + 0.5) = round(bin) for bin >= 0; 36 -> slot 36 = bin 0
+                const float m = (__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * gi) * gj;
+#if !(defined(SIFTMI_ORI_ABL) && SIFTMI_ORI_ABL == 1)
+                lds_add_bits(hist_lds + ((unsigned)b << 2), 0, m);
+#else
+                asm volatile("; histogram add elided" :: "v"(b), "v"(m));
+#endif
             };
 #if defined(SIFTMI_ORI_ABL) && SIFTMI_ORI_ABL == 2               // tools: a keypoint's prologue and tail alone (no sample is visited)
             if (total < 0)
 #endif
-            if (interior) {
+            if (interior && tabled) {
                 // Round 5: an interior window is walked in QUADS, as the descriptor's: four consecutive samples of a window row per lane
-                // and trip (the last quad of a row runs up to three columns past the window: those samples get weight 0).  The index
-                // arithmetic, the row term of the weight and the address are shared, the row's texels arrive as three wide loads and one
-                // b64 instead of sixteen dword loads; every sample's own arithmetic is the expression of `sample` above, so the same
-                // values go to the same bins (order-free u64 sums: identical histograms).
+                // and trip (the last quad of a row runs up to three columns past the window: the table's weight there is 0).  The index
+                // arithmetic, the row's weight and the address are shared, the row's texels arrive as three wide loads and one b64.
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 const int qpr = (side + 3) >> 2, total_q = side * qpr;
                 const float inv_qpr = 1.0f / (float)qpr;
                 for (int q = lidx; q < total_q; q += STRIDE) {
                     const int jj = (int)(((float)q + 0.5f) * inv_qpr), k4 = (q - jj * qpr) << 2;
-                    const int j = jj - r, i0 = k4 - r, nv = side - k4;                       // nv >= 1 samples of this row from i0 on
-                    const int c = __mul24(y + j - 1, g.pitch) + ((x + i0 - 1) << 2);       // texel (x + i0 - 1, y + j - 1)
+                    const int c = __mul24(y + jj - r - 1, g.pitch) + ((x + k4 - r - 1) << 2);     // texel (x + i0 - 1, y + j - 1), i0 = k4 - r, j = jj - r
                     const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);           // row y + j: columns x + i0 - 1 ... + 2
                     const u32x2 rb = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);       //            ... + 3, + 4
                     const u32x4 ru = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);             // row y + j - 1: columns x + i0 ... + 3
                     const u32x4 rd = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);   // row y + j + 1
+                    const float gj = otab[jj];
+                    const float *gq = otab + k4;
+                    const float G[4] = {gq[0], gq[1], gq[2], gq[3]};
                     const float A[6] = {__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w),
                                         __uint_as_float(rb.x), __uint_as_float(rb.y)};
                     const float U[4] = {__uint_as_float(ru.x), __uint_as_float(ru.y), __uint_as_float(ru.z), __uint_as_float(ru.w)};
                     const float D[4] = {__uint_as_float(rd.x), __uint_as_float(rd.y), __uint_as_float(rd.z), __uint_as_float(rd.w)};
-                    const float v = (float)j * inv_sigma, vv = v * v;
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++) {
-                        const float u = (float)(i0 + s4) * inv_sigma;
-                        const float wgt = s4 < nv ? __builtin_amdgcn_exp2f(fmaf(u, u, vv) * k_exp) : 0.0f;
-                        // the gradient is (dx, dy) / 2 (SIFTGradient.metal:31-32): halving is exact, so the angle is that of (dx, dy) (the
-                        // octant quotient's mantissa does not see a common power of two) and |gradient| = sqrt(dx^2 + dy^2) / 2 with the 1/2
-                        // folded into the fixed-point scale -- two multiplies less per sample, the same bits.  |angle| <= pi puts the bin
-                        // in [-18, 18]: one wrap.
-                        const float dx = A[s4 + 2] - A[s4], dy = D[s4] - U[s4];
-                        const float orientation = atan2_lean(dx, dy);
-                        const float magnitude2 = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
-                        int bin = (int)roundf(orientation * (float)(ORI_BINS / (2.0 * 3.14159265358979323846)));
-                        if (bin < 0) bin += ORI_BINS;
-                        atomicAdd(&hist[bin], fix32_product(wgt * magnitude2, 2147483648.0f));
-                    }
+                    for (int s4 = 0; s4 < 4; s4++) accumulate(A[s4 + 2] - A[s4], D[s4] - U[s4], G[s4], gj);
                 }
             } else {
-                for (int idx = lidx; idx < total; idx += STRIDE) sample(std::false_type{}, idx);
+                // windows that touch the image border (mirror edges; outside the image -> gradient (0, 0)), or wider than the table
+                for (int idx = lidx; idx < total; idx += STRIDE) {
+                    const int jj = (int)(((float)idx + 0.5f) * inv_side), ii = idx - jj * side;
+                    const int gx = x + ii - r, gy = y + jj - r;
+                    float dx = 0.0f, dy = 0.0f;
+                    if (gx >= 0 && gy >= 0 && gx < w && gy < h) {
+                        const int pxx = symm(gx + 1, w), mxx = symm(gx - 1, w), pyy = symm(gy + 1, h), myy = symm(gy - 1, h);
+                        auto rd = [&](int xx, int yy) -> float { return (xx < 0 || yy < 0 || xx >= w || yy >= h) ? 0.0f : g.g[(size_t)yy * w + xx]; };
+                        dx = rd(pxx, gy) - rd(mxx, gy);
+                        dy = rd(gx, pyy) - rd(gx, myy);
+                    }
+                    accumulate(dx, dy, tabled ? otab[ii] : gauss(ii - r), tabled ? otab[jj] : gauss(jj - r));
+                }
             }
         }
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the keypoint
         __threadfence_block();
         const int li = lane < ORI_BINS ? lane : 0;
-        unsigned long long hsum = hist0[li];
+        unsigned hsum = 0u;
 #pragma unroll
-        for (int c = 1; c < OCOPY; c++) hsum += hist0[c * OSTRIDE + li];
-        float hv = from_fix32(hsum);
+        for (int c = 0; c < OCOPY; c++) hsum += hist0[c * OSTRIDE + li] + (li == 0 ? hist0[c * OSTRIDE + ORI_BINS] : 0u);
+        float hv = (float)hsum * ldexpf(1.0f, -24 + 2 * half_shift);
         const int lm = (li + ORI_BINS - 1) % ORI_BINS, lp = (li + 1) % ORI_BINS;
         for (int it = 0; it < prm.ori_smoothing; it++) {               // :67-84
             const float h0 = __shfl(hv, lm), h2 = __shfl(hv, lp);
@@ -1109,32 +1138,57 @@ __device__ __forceinline__ float wave_sum(float v) {
 // idles at workgroup tails on dense frames (4.35 of 6 resident, PMC round 4)
 #ifndef SIFTMI_DESC_WAVES
 #define SIFTMI_DESC_WAVES 7                                // wavefronts per SIMD the descriptor kernel's register budget is sized for (72 VGPRs);
-                                                           // the one-wavefront form of large launches: one more (64 VGPRs, 16 B of scratch outside the
-                                                           // loop, 4.9 KB of LDS per wavefront): 5.52-5.55 against 5.56-5.72 ms on dense frames
+                                                           // the one-wavefront form of large launches: one more (64 VGPRs)
 #endif
+// Round 6 -- histogram contributions as DENORMAL floats.  The sample loop is bound by vector issue and its instructions are not equal
+// (tools/ubench/ubench_mix.hip, profiles/ubench_mix_r06.log: add / mul / fma 1.1 ns per wavefront and SIMD, compares / conversions / floor /
+// fract / shifts / min / max 1.9, v_exp / v_rcp / v_sqrt 3.5; summed over the loop's listing that model gives the measured 5.5 ms).  Rounds
+// 2-5 converted every contribution to 2^-32 fixed point (fma + v_cvt_u32_f32, 3.0 ns, eight per sample).  Now the Gaussian weight carries a
+// factor 2^-126 (2^-63 in either table entry), which puts every contribution c = w_xy w_bin |gradient| weight into the denormal / first
+// normal binade of f32, where the BIT PATTERN of a float is its value in units of 2^-149: __float_as_uint(product) is round-to-nearest-even
+// of c 2^24 (|gradient| <= sqrt(2) / 2 keeps it below 2^24, the end of the linear range; gfx950 multiplies denormals at full rate, same log),
+// and goes to a u32 LDS add as it is: 1.1 ns per contribution.  Still order-free integer sums (bit-reproducible, every launch form gives the
+// same bytes), now with 24 fractional bits instead of 32: rounding 3e-8 per contribution in the reference's units, ~3e-7 per bin, against bin
+// totals of 0.1 ... 30 -- this is where the precision budget of the stated 1e-4 goes (measured: profiles/desc_margin_r06.log).
+// A bin total stays below (hw + 1)^2 sqrt(2) / 2 (the samples of a cell's support times their bilinear weights); `unit_shift` scales the
+// contributions down by a power of two for windows so large that this passes 2^8 (never with the reference's schedule: hw <= 11).
+//
+// Also round 6 (all byte-neutral between launch forms, all inside the tolerances):
+//  * exp(-(rx^2 + ry^2) / 8) = exp(-j^2 / 8 hw^2) exp(-i^2 / 8 hw^2) (a rotation keeps j^2 + i^2): one table of 2 radius + 4 entries per
+//    descriptor in LDS, built by the wavefront (two v_exp per lane), read per quad (row entry + four column entries) instead of
+//    mul, fma, mul, v_exp per sample;
+//  * ten orientation slots per cell -- bins 0 ... 7, slot 8 = bin 0 again, slot 9 only ever receives zeros -- so that the upper
+//    orientation bin is the lower one's neighbour in memory (an immediate offset; no second address, no wrap), and the slot index is
+//    formed in float (two fmas and ONE conversion for the byte address instead of three conversions and seven integer operations);
+//  * floor by v_floor_f32, fraction by subtraction (exact), range tests on the bits of the floor (0 <= f <= 3 is one unsigned compare);
+//  * no early exit per sample: a wavefront never skips it (64 lanes, ~90 % of them inside), and the cell tests reject what it rejected;
+//  * quads run up to three candidates past a row's interval without masking them: the interval is conservative and a candidate beyond
+//    the window's radius cannot pass the cell tests ((radius + 1)^2 > 12.5 hw^2 >= rx^2 + ry^2 of anything inside).
 // PATCH (siftmi_config.descriptor_patch_lds; BASELINE north_star: "LDS tile staging for ... 16x16 descriptor patches"): an interior window
 // is walked in 16 x 16-sample tiles of its bounding box; a tile's 18 x 18 texels (the samples and their +-1 neighbours) are copied into
 // LDS once and every lane takes the four samples of one quarter row from there.  Same samples, same arithmetic, order-free bins:
 // byte-identical descriptors (tests/test_gpu_parity.py::test_descriptor_patch_staging_is_byte_identical).  It is NOT the default: a
 // window's texels are used ~4 times each and the L1 / L2 already serve that (profiles/pmc_descriptor_dense_r05.txt: 0.9 MB fetched from HBM
 // by 2 M workgroups), while tiles of the bounding box visit the corners the compacted row walk skips and every 256 samples wait for a
-// load -> LDS -> read round trip: 13.4 against 5.5 ms per 1.13 M descriptors on dense frames (profiles/desc_patch_lds_r05.log).
+// load -> LDS -> read round trip (profiles/desc_patch_lds_r05.log; the PATCH form needs 5 wavefronts' worth of registers per SIMD and says so).
 template <bool COOP, int WPB = 4, bool PATCH = false>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI_DESC_WAVES + (WPB == 1 ? 1 : 0)))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH ? 5 : SIFTMI_DESC_WAVES + (WPB == 1 ? 1 : 0)))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
                                                         float *__restrict__ desc_f32 /* may be null */) {
-    // NCOPY private copies of the 4x4x8 histogram per wave (copy = lane % NCOPY): neighbouring lanes take neighbouring samples,
-    // which mostly fall into the same cell and bin, and same-address lanes of one ds_add_u64 serialise (6 cycles distinct, 26
-    // at 4 lanes per address).  The copies of a bin are INTERLEAVED (u64 index = slot * NCOPY + copy, round 3): four
-    // neighbouring lanes that hit the same bin then touch four neighbouring banks.  (Rounds 1-2 kept the copies 128 u64 =
-    // 1024 B apart -- the same bank for every copy of a bin, so the copies removed the same-address serialisation and put a
-    // 4-way bank conflict in its place: 72 % of the kernel's LDS cycles in the PMC run.  129 u64 apart cost more address
-    // arithmetic than it saved.)  u64 fixed point: see fix32_product.
+    // NCOPY private copies of the histogram per wave (copy = lane % NCOPY): neighbouring lanes take neighbouring samples, which mostly
+    // fall into the same cell and bin, and same-address lanes of one LDS add serialise.  The copies of a slot are INTERLEAVED (u32 index
+    // = slot * NCOPY + copy, round 3): four neighbouring lanes that hit the same bin then touch four neighbouring banks.
     constexpr int NCOPY = SIFTMI_DESC_NCOPY;
+    constexpr int NSLOT = 10;                              // orientation slots per cell (see above)
+    constexpr int HIST = 16 * NSLOT * NCOPY;               // u32 per histogram
     constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
     static_assert(WPB == 4 || (!COOP && WPB == 1), "COOP shares one descriptor among the four wavefronts of a workgroup");
-    __shared__ unsigned long long patch_all[WPB][NCOPY * DESC_N];
+    // The address of a contribution is that of cell (fx, fy) with fx, fy >= -1 (a corner at -1 is reached through its neighbour at 0 by an
+    // immediate offset), i.e. up to 5 NSLOT slots below the histogram: PAD keeps that address non-negative for the first histogram too.
+    constexpr int PAD = 5 * NSLOT * NCOPY;
+    __shared__ unsigned hist_all[PAD + WPB * HIST];
+    __shared__ float gtab_all[WPB][MAXCOL + 4];            // exp(-k^2 / 8 hw^2) 2^-63 (2^-unit_shift folded in), k = -radius ... radius + 3
     __shared__ short col_start_all[WPB][MAXCOL + 2];          // walk index of a row's first candidate (<= 128 * 128 / 1: fits 15 bits)
     __shared__ short col_lo_all[WPB][MAXCOL];
     __shared__ short col_len_all[WPB][MAXCOL];
@@ -1145,8 +1199,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
     const int hw_ = COOP ? 0 : wv;                          // whose histogram copies: the workgroup's (COOP) or this wave's
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
     const int lidx = COOP ? (int)threadIdx.x : lane;
-    unsigned long long *patch0 = patch_all[hw_];
-    unsigned long long *patch = patch0 + (lane & (NCOPY - 1));           // this lane's copy; bin slot k sits at patch[k * NCOPY]
+    unsigned *hist0 = hist_all + PAD + hw_ * HIST;
+    // byte address (LDS) of this lane's copy of slot 0, as a float: a contribution's address is formed in float (exact: < 2^24)
+    const float hist_base_f = (float)((unsigned)(size_t)(lds_u32_t *)hist0 + 4u * (unsigned)(lane & (NCOPY - 1)));
+    float *gtab = gtab_all[wv];
     short *col_start = col_start_all[wv];
     short *col_lo = col_lo_all[wv];
     short *col_len = col_len_all[wv];
@@ -1169,14 +1225,24 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         const int ipx = (int)px, ipy = (int)py;
         // the whole window and the +-1 neighbours of its samples lie inside the image: no mirror, no range test per sample
         const bool interior = ipx - radius >= 1 && ipx + radius <= w - 2 && ipy - radius >= 1 && ipy + radius <= h - 2;
+        const int side = 2 * radius + 1;
+        const bool compact = side <= MAXCOL;
+        // Gaussian weight of a sample = gauss(j) gauss(i) with gauss(k) = exp2(kg k^2) 2^-63 2^-(unit_shift / 2): the product carries 2^-126
+        // (and 2^-unit_shift); kg = -log2(e) / (8 hw^2).  unit_shift (even): 0 while a bin's bound (hw + 1)^2 sqrt(2) / 2 stays below 2^8.
+        const float kg = (in.inv_hw * in.inv_hw) * (-0.125f * 1.44269504088896341f);
+        const float bound = (histogramWidth + 1.0f) * (histogramWidth + 1.0f) * 0.70710678f;
+        int half_shift = 0;
+        while (ldexpf(bound, -2 * half_shift) >= 240.0f) half_shift++;       // (wave-uniform; no trip with the reference's schedule)
+        const float gscale = ldexpf(1.0f, -63 - half_shift);
+        auto gauss = [&](int k) -> float { const float f = (float)k; return __builtin_amdgcn_exp2f(kg * (f * f)) * gscale; };
 
         if (COOP) {
             __syncthreads();                                                          // wave 0 is done reading the previous descriptor's bins
-            for (int c = threadIdx.x; c < NCOPY * DESC_N; c += 256) patch0[c] = 0ull;
+            for (int c = threadIdx.x; c < HIST; c += 256) hist0[c] = 0u;
         } else {
-            for (int c = lane; c < NCOPY * DESC_N; c += 64) patch0[c] = 0ull;             // all copies (contiguous)
+            for (int c = lane; c < HIST; c += 64) hist0[c] = 0u;                          // all copies (contiguous)
         }
-        const int side = 2 * radius + 1;
+        if (compact) for (int k = lane; k < side + 3; k += 64) gtab[k] = gauss(k - radius);
 
         // The reference visits every (j, i) of the (2 radius + 1)^2 window (metal :194-195), but a sample adds
         // something only if its cell coordinates fall inside (-1, 4)^2, i.e. inside a rotated square of half
@@ -1184,17 +1250,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         // qualify form one interval; compute a conservative interval per row (+-2 px of float slack), prefix-sum the
         // lengths and walk the compacted index space, so that all 64 lanes hold candidate samples.  The exact
         // per-sample test below is unchanged, hence exactly the same samples contribute; the bins are order-free
-        // (u64 fixed point), so walking row-major instead of the reference's column-major changes nothing -- but
+        // (integer sums), so walking row-major instead of the reference's column-major changes nothing -- but
         // neighbouring lanes then read neighbouring pixels: the four gradient loads of a wavefront touch 3-4 cache
         // lines instead of 64 each (round 1 walked columns: every lane its own line, the texture path was the limit).
-        // Round 5: an INTERIOR window is walked in QUADS -- four consecutive candidates of a row per lane and trip (the last quad of a
-        // row is partly past its interval; those samples are given an x offset that fails the exact test).  The walk's table look-up
-        // and the loads' address arithmetic are then paid once per four samples, the row's texels arrive as four wide loads instead of
-        // sixteen dword loads, and the terms of the rotated coordinates that depend on the row alone are shared; the exact per-sample
-        // arithmetic is unchanged, so the same samples add the same values (order-free bins: bit-identical descriptors).  The loop is
-        // bound by vector issue (ablation, profiles/desc_ablation_r05.log: without its LDS atomics it is no faster), ~150 -> ~125
-        // instructions per sample.
-        const bool compact = side <= MAXCOL;
+        // Round 5: an INTERIOR window is walked in QUADS -- four consecutive candidates of a row per lane and trip.  The walk's table
+        // look-up and the loads' address arithmetic are then paid once per four samples, the row's texels arrive as four wide loads
+        // instead of sixteen dword loads, and the terms of the rotated coordinates that depend on the row alone are shared.
         const int unit = (compact && interior) ? 4 : 1;                   // candidates per walk index
         int total;
         if (compact) {
@@ -1227,7 +1288,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                 int incl = nun;                                            // inclusive wave prefix sum
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-                if (cidx < side) { col_start[cidx] = (short)(run + incl - nun); col_lo[cidx] = (short)lo; col_len[cidx] = (short)len; }
+                if (cidx < side) { col_start[cidx] = (short)(run + incl - nun); col_lo[cidx] = (short)lo; if (PATCH) col_len[cidx] = (short)len; }
                 run += __shfl(incl, 63);
             }
             total = run;
@@ -1235,31 +1296,27 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         } else {
             total = side * side;
         }
-        if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // bins cleared (COOP: by all four waves); column table of this wave written
+        if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // bins cleared (COOP: by all four waves); tables of this wave written
         __threadfence_block();
 
-        // One sample (j = x offset, i = y offset) of the window: SIFTDescriptor.metal:197-222.  INTERIOR (wave-uniform, almost
-        // every descriptor): the sample and its four neighbours are inside the image, so the gradient is four loads at one
-        // 32-bit offset (the rows above and below through an SGPR addend) and there is no per-sample range test or mirror.
-#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1             // tools: every histogram add replaced by register arithmetic (the loop without its LDS atomics)
-        unsigned long long abl_acc = 0ull;
-#define DESC_HADD(p, v) do { const unsigned long long v_ = (v); asm volatile("; histogram add elided" :: "v"((unsigned)v_), "v"((unsigned)(size_t)(p))); } while (0)
+        // One sample (x offset fj, y offset i) of the window: SIFTDescriptor.metal:197-222.  gj, gi: gauss(j), gauss(i) (gj = 0 for a
+        // candidate that is not a window sample).  INTERIOR (wave-uniform, almost every descriptor): the sample and its four neighbours
+        // are inside the image, so the texels come from the walk (wide loads) and there is no per-sample range test or mirror.
+#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1             // tools: every histogram add elided (the loop without its LDS atomics)
+#define DESC_HADD(a, off, v) asm volatile("; histogram add elided" :: "v"(a), "v"(v))
 #else
-#define DESC_HADD(p, v) atomicAdd((p), (v))
+#define DESC_HADD(a, off, v) lds_add_bits((a), (off), (v))
 #endif
-        auto sample = [&](auto interior_tag, int j, int i, float t_xp, float t_xm, float t_yp, float t_ym) {
+        auto sample = [&](auto interior_tag, float fj, int i, float gj, float gi, float t_xp, float t_xm, float t_yp, float t_ym) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
-            const float fj = (float)j, fi = (float)i;
+            const float fi = (float)i;
             const float rx = fmaf(fj, cs, -(fi * sn));                     // (j cosT - i sinT) / histogramWidth
             const float ry = fmaf(fj, sn, fi * cs);                        // (j sinT + i cosT) / histogramWidth
-            // every trilinear corner of this sample lies outside the 4x4 grid (addValue :66-68 drops all 8 contributions): bx, by outside
-            // (-1, 4).  Tested on rx, ry: for |rx| in [2, 2.5] the sum rx + 1.5 is exact (both are multiples of 2^-22 and so is every float
-            // of the result's binade), so bx >= 4 <=> rx >= 2.5 and bx <= -1 <=> rx <= -2.5 -- two compares with |.| instead of min / max / 2.
-            if (!(fabsf(rx) < 2.5f && fabsf(ry) < 2.5f)) return;
-            const float bx = rx + 1.5f, by = ry + 1.5f;                    // + d / 2 - 0.5
+            const float bx = rx + 1.5f, by = ry + 1.5f;                    // + d / 2 - 0.5: cell coordinates; the reference drops a sample
+                                                                           // unless both lie in (-1, 4) (addValue :66-68): the cell tests below
             float dx, dy;                                                  // central differences, not yet halved
             if (INTERIOR) {
-                dx = t_xp - t_xm;                                          // the four texels were requested one trip ahead (walk)
+                dx = t_xp - t_xm;
                 dy = t_yp - t_ym;
             } else {
                 // ushort2(px + j, py + i): truncation toward zero, (-1, 0) -> 0; negative: no texel
@@ -1278,34 +1335,31 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
             // vector (x = ty, y = tx) rotated by -theta; its direction does not depend on the factor 1/2
             const float xr = fmaf(dy, cosT, dx * sinT), yr = fmaf(dx, cosT, -(dy * sinT));
             const float bin = octant_bin(yr, xr);                          // in [0, 8]
-            // value = |gradient| exp(-(rx^2 + ry^2) / 8) in units of 2^-32: |gradient| = sqrt(dx^2 + dy^2) / 2
-            // (the factor -1/8 is a power of two: folding it into log2(e) gives the bits of __expf(-(rx^2 + ry^2) / 8))
-            const float wgt = __builtin_amdgcn_exp2f(fmaf(rx, rx, ry * ry) * (-0.125f * 1.44269504088896341f));
-            const float v32 = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * (wgt * 2147483648.0f);
+            // value = |gradient| exp(-(rx^2 + ry^2) / 8) 2^-126: |gradient| = sqrt(dx^2 + dy^2) / 2, so `v` is the value in units of
+            // 2^-24 2^-149 -- at most sqrt(2) 2^-126, inside the range where a float's bits are linear in its value
+            const float v = (__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * gj) * gi;
             {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
-                // and bin wrap (:59-79); here one test per cell corner, the two orientation bins wrapped once (bin lies in
-                // [0, 8]: floor can reach 8, never go negative).
+                // and bin wrap (:59-79); here one test per cell corner, and the upper orientation bin is the next slot.
                 // The "upper" corner is floor + 1 here, not ceil: they differ only when the coordinate is an integer, and then
                 // the upper corner's weight is exactly 0 -- it adds 0 whichever cell or bin it names.
-                // floor and fraction by v_cvt_flr_i32_f32 / v_fract_f32 (2 instead of 3 instructions per coordinate).  v_fract is
-                // x - floor(x) unless that rounds up to 1.0, which cannot happen here: bin >= 0, and a negative bx (by) is a multiple of
-                // 2^-23 (the sum of 1.5 and an rx in [-2.5, -1.5)), so bx + 1 is exact.
-                int cax, cay, cab;
-                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(cax) : "v"(bx));
-                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(cay) : "v"(by));
-                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(cab) : "v"(bin));
-                const int ba = cab & 7, bb = (cab + 1) & 7;
-                const float iMax = __builtin_amdgcn_fractf(bx), iMin = 1.0f - iMax;
-                const float jMax = __builtin_amdgcn_fractf(by), jMin = 1.0f - jMax;
-                const float bMax = __builtin_amdgcn_fractf(bin), bMin = 1.0f - bMax;
-                const bool xa = (unsigned)cax < 4u, xb = (unsigned)(cax + 1) < 4u, ya = (unsigned)cay < 4u, yb = (unsigned)(cay + 1) < 4u;
-                const float va = bMin * v32, vb = bMax * v32;              // the value's share of either orientation bin
-                const int c00 = (cay * 32 + cax * 8) * NCOPY;              // u64 index of cell (cax, cay), bin 0, copy 0
-                unsigned long long *pa = patch + c00 + ba * NCOPY, *pb = patch + c00 + bb * NCOPY;
-                if (xa && ya) { const float wxy = iMin * jMin; DESC_HADD(pa, fix32_product(wxy, va)); DESC_HADD(pb, fix32_product(wxy, vb)); }
-                if (xb && ya) { const float wxy = iMax * jMin; DESC_HADD(pa + 8 * NCOPY, fix32_product(wxy, va)); DESC_HADD(pb + 8 * NCOPY, fix32_product(wxy, vb)); }
-                if (xb && yb) { const float wxy = iMax * jMax; DESC_HADD(pa + 40 * NCOPY, fix32_product(wxy, va)); DESC_HADD(pb + 40 * NCOPY, fix32_product(wxy, vb)); }
-                if (xa && yb) { const float wxy = iMin * jMax; DESC_HADD(pa + 32 * NCOPY, fix32_product(wxy, va)); DESC_HADD(pb + 32 * NCOPY, fix32_product(wxy, vb)); }
+                // x - floor(x) is exact (no rounding) for the finite values here.
+                const float fx = __builtin_floorf(bx), fy = __builtin_floorf(by), fb = __builtin_floorf(bin);
+                const float iMax = bx - fx, iMin = 1.0f - iMax;
+                const float jMax = by - fy, jMin = 1.0f - jMax;
+                const float bMax = bin - fb, bMin = 1.0f - bMax;
+                // cell c in {0, 1, 2, 3} <=> bits(c) <= bits(3.0f): negative floors have the sign bit set, larger ones larger bits (the
+                // floor of a value in [0, 1) is +0)
+                const bool xa = __float_as_uint(fx) <= 0x40400000u, xb = __float_as_uint(fx + 1.0f) <= 0x40400000u;
+                const bool ya = __float_as_uint(fy) <= 0x40400000u, yb = __float_as_uint(fy + 1.0f) <= 0x40400000u;
+                const float va = bMin * v, vb = bMax * v;                  // the value's share of either orientation bin
+                // byte address of slot ((fy 4 + fx) NSLOT + fb), this lane's copy: exact in float (garbage where no test passes)
+                const float slot = fmaf(fy, (float)(4 * NSLOT), fmaf(fx, (float)NSLOT, fb));
+                unsigned a;
+                asm("v_cvt_u32_f32 %0, %1" : "=v"(a) : "v"(fmaf(slot, (float)(4 * NCOPY), hist_base_f)));
+                if (xa && ya) { const float wxy = iMin * jMin; DESC_HADD(a, 0, wxy * va); DESC_HADD(a, NCOPY, wxy * vb); }
+                if (xb && ya) { const float wxy = iMax * jMin; DESC_HADD(a, NSLOT * NCOPY, wxy * va); DESC_HADD(a, (NSLOT + 1) * NCOPY, wxy * vb); }
+                if (xb && yb) { const float wxy = iMax * jMax; DESC_HADD(a, 5 * NSLOT * NCOPY, wxy * va); DESC_HADD(a, (5 * NSLOT + 1) * NCOPY, wxy * vb); }
+                if (xa && yb) { const float wxy = iMin * jMax; DESC_HADD(a, 4 * NSLOT * NCOPY, wxy * va); DESC_HADD(a, (4 * NSLOT + 1) * NCOPY, wxy * vb); }
             }
         };
         auto walk = [&](auto interior_tag) {
@@ -1338,7 +1392,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                         const int r = lane >> 2, q4 = (lane & 3) << 2;  // this lane: sample row r of the tile, columns q4 ... q4 + 3
                         const int srow = ty * 16 + r;
                         int lo = 0, len = 0;
-                        if (srow < side) { lo = col_lo[srow]; len = col_len[srow]; }
+                        float gi = 0.0f;
+                        if (srow < side) { lo = col_lo[srow]; len = col_len[srow]; gi = gtab[srow]; }
                         const float *tc = tile + (r + 1) * TP + q4;     // texel x - 1 of the quad's first sample, its own row
                         float A[6], U[4], D[4];
 #pragma unroll
@@ -1348,7 +1403,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
 #pragma unroll
                         for (int s4 = 0; s4 < 4; s4++) {
                             const int j = j0 + q4 + s4;
-                            sample(interior_tag, (j >= lo && j < lo + len) ? j : 30000, i0 + r, A[s4 + 2], A[s4], D[s4], U[s4]);
+                            const bool valid = j >= lo && j < lo + len;       // (inside a row interval => a window sample: the table holds it)
+                            sample(interior_tag, valid ? (float)j : 30000.0f, i0 + r, valid ? gtab[j + radius] : 0.0f, gi, A[s4 + 2], A[s4], D[s4], U[s4]);
                         }
                     }
                 }
@@ -1371,44 +1427,39 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                     i = ii - radius; j = idx - ii * side - radius;
                 }
             };
+            auto gauss_at = [&](int k) -> float { return compact ? gtab[k + radius] : gauss(k); };   // (the table holds gauss(k): same bits)
             if constexpr (INTERIOR) {
                 if (lidx >= total) return;
                 if (compact) {
                     // quads: row y holds texels x - 1 ... x + 4 of the quad's four samples x ... x + 3 (b128 + b64), rows y - 1 and y + 1
-                    // texels x ... x + 3 (b128 each).  A partial last quad reads up to three texels past its row's interval -- inside the
-                    // image row, the next row, or past the layer's end where the range-checked buffer returns 0 -- and never uses them.
-                    // No software pipelining here: a trip is ~400 vector instructions, the other wavefronts of the SIMD (7 in the one-wavefront form) cover its
-                    // one memory latency, and the 14 registers a prefetched quad would hold cost a resident wavefront (measured equal
-                    // or 1-2 % behind with the prefetch, profiles/desc_variants_r05.log).
-                    auto locate_q = [&](int q, int &j0, int &i, int &nv) {
-                        while (q >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }
-                        const int k4 = (q - cur_start) << 2;
-                        i = cur - radius;
-                        j0 = (int)col_lo[cur] + k4;
-                        nv = (int)col_len[cur] - k4;                           // >= 1 candidates from j0 on in this row
-                    };
+                    // texels x ... x + 3 (b128 each).  The last quad of a row runs up to three candidates past its interval: their texels
+                    // come from the image row, the next row or the next layer (a described layer is never the stack's last: scale <= nspo),
+                    // or read 0 past the allocation (range-checked buffer); the cell tests reject them (header).
+                    // No software pipelining here: a trip is ~300 vector instructions, the other wavefronts of the SIMD cover its one
+                    // memory latency, and the 14 registers a prefetched quad would hold cost a resident wavefront
+                    // (measured equal or 1-2 % behind with the prefetch, profiles/desc_variants_r05.log).
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    auto fetch_q = [&](int j0, int i, u32x4 &a, u32x2 &a2, u32x4 &u, u32x4 &d) {
-                        const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j0 - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
-                        a = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);
-                        a2 = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);
-                        u = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);
-                        d = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);
-                    };
                     for (int q = lidx; q < total; q += STRIDE) {
-                        int j0, i, nv;
-                        u32x4 a, u, d;
-                        u32x2 a2;
-                        locate_q(q, j0, i, nv);
-                        fetch_q(j0, i, a, a2, u, d);
+                        while (q >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }
+                        const int i = cur - radius;
+                        const int j0 = (int)col_lo[cur] + ((q - cur_start) << 2);
+                        const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j0 - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);
+                        const u32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);
+                        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);
+                        const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);
+                        const float gi = gtab[cur];
+                        const float *gq = gtab + (j0 + radius);
+                        const float G[4] = {gq[0], gq[1], gq[2], gq[3]};
+                        const float fj0 = (float)j0;
                         const float A[6] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
                                             __uint_as_float(a2.x), __uint_as_float(a2.y)};
                         const float U[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
                         const float D[4] = {__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w)};
 #pragma unroll
                         for (int s4 = 0; s4 < 4; s4++)
-                            sample(interior_tag, s4 < nv ? j0 + s4 : 30000, i, A[s4 + 2], A[s4], D[s4], U[s4]);
+                            sample(interior_tag, fj0 + (float)s4, i, G[s4], gi, A[s4 + 2], A[s4], D[s4], U[s4]);
                     }
                     return;
                 }
@@ -1427,14 +1478,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                     float b0, b1, b2, b3;
                     locate(min(idx + STRIDE, total - 1), jn, in_);
                     fetch(jn, in_, b0, b1, b2, b3);
-                    sample(interior_tag, j, i, a0, a1, a2, a3);
+                    sample(interior_tag, (float)j, i, gauss_at(j), gauss_at(i), a0, a1, a2, a3);
                     j = jn; i = in_; a0 = b0; a1 = b1; a2 = b2; a3 = b3;
                 }
             } else {
                 for (int idx = lidx; idx < total; idx += STRIDE) {
                     int j, i;
                     locate(idx, j, i);
-                    sample(interior_tag, j, i, 0.0f, 0.0f, 0.0f, 0.0f);
+                    sample(interior_tag, (float)j, i, gauss_at(j), gauss_at(i), 0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
         };
@@ -1442,16 +1493,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         if (total < 0)
 #endif
         if (interior) walk(std::true_type{}); else walk(std::false_type{});
-#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1
-        if (abl_acc == 0x123456789abcdefull) atomicAdd(patch, abl_acc);
-#endif
 #undef DESC_HADD
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
         __threadfence_block();
-        unsigned long long a0 = 0ull, a1 = 0ull;                           // bins lane and lane + 64: their NCOPY copies are adjacent
+        // features lane and lane + 64 (feature = cell * 8 + bin): the NCOPY copies of their slot, and for bin 0 those of slot 8 (the other
+        // bins read slot 9, which only ever received zeros).  Sums stay below 2^32 (header).
+        unsigned a0 = 0u, a1 = 0u;
+        {
+            const int cell = lane >> 3, b = lane & 7;
+            const unsigned *s0 = hist0 + (cell * NSLOT + b) * NCOPY, *s1 = s0 + 8 * NSLOT * NCOPY;
+            const int alias = ((b == 0 ? 8 : 9) - b) * NCOPY;
 #pragma unroll
-        for (int c = 0; c < NCOPY; c++) { a0 += patch0[lane * NCOPY + c]; a1 += patch0[(64 + lane) * NCOPY + c]; }
-        float f0 = from_fix32(a0), f1 = from_fix32(a1);
+            for (int c = 0; c < NCOPY; c++) { a0 += s0[c] + s0[alias + c]; a1 += s1[c] + s1[alias + c]; }
+        }
+        const float unit_scale = ldexpf(1.0f, -24 + 2 * half_shift);        // back to the reference's units (the normalisation removes it again)
+        float f0 = (float)a0 * unit_scale, f1 = (float)a1 * unit_scale;
         {   // normalise -> clamp 0.2 -> normalise (:15-39, :224-227)
             float dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));
             f0 *= dn; f1 *= dn;
