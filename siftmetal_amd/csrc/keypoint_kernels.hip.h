@@ -815,6 +815,25 @@ __device__ __forceinline__ float octant_bin36(float y, float x) {
     return y < 0.0f ? 36.0f - r : r;
 }
 
+// Round 6: atan2(y, x) / 2 pi in (-0.5, 0.5] by the half-angle tangent.  With m = |(x, y)| (which both sample loops need anyway):
+// tan(a / 2) = y / (m + x); taking |x| folds the angle into [-pi/2, pi/2] (|t| <= 1, sign of y kept, no octant swap: no min / max), and
+// x < 0 reflects it, pi - a' for either sign of y.  Same six-term polynomial (here / pi: atan(t) / pi = a' / 2 pi); 1.2e-6 rad worst
+// case (tools/fit_atan.py; the argument of atan is half the angle, so the fit's error doubles).  Against octant_bin: one reflection
+// instead of three, no v_max3 / v_min -- ~8 ns of ~45 per sample at the measured issue costs (profiles/ubench_mix_r06.log).
+// m must be > 0 (the callers add 1e-30 under the root: a normal number -- v_sqrt_f32 flushes denormal inputs), so (0, 0) gives 0 like atan2f.
+__device__ __forceinline__ float angle_turns(float y, float x, float m) {
+    const float t = y * __builtin_amdgcn_rcpf(m + fabsf(x));
+    const float s = t * t;
+    float q = 2.347153146e-03f;
+    q = fmaf(q, s, -1.130612474e-02f);
+    q = fmaf(q, s, 2.615457028e-02f);
+    q = fmaf(q, s, -4.264957085e-02f);
+    q = fmaf(q, s, 6.322221458e-02f);
+    q = fmaf(q, s, -1.060780212e-01f);
+    const float r = t * fmaf(s, q, 0.318309886183790672f);
+    return x < 0.0f ? 0.5f - r : r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gradient on demand: SIFTGradient.metal:15-39 (atan2(tx, ty) -- argument order as in the
 // reference -- and |grad| of central differences, mirror edges); outside the image -> (0, 0).
@@ -878,8 +897,8 @@ __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, 
 // WPB: wavefronts per workgroup (COOP = false), see descriptor_kernel
 // Round 6 (as the descriptor's sample loop; costs in profiles/ubench_mix_r06.log): contributions are denormal floats whose bits go to a u32
 // LDS add (24 fractional bits); the Gaussian weight exp(-(i^2 + j^2) / 2 lambda^2 sigma^2) is the product of two entries of a per-keypoint
-// table (zero past the window: the padding of a row's last quad needs no mask); the bin is formed directly in units of 10 degrees in
-// [0, 36] (octant_bin36: no scaling, no wrap of a negative angle) and rounded by one conversion, slot 36 being bin 0 again.
+// table (zero past the window: the padding of a row's last quad needs no mask); the angle comes in turns from the half-angle tangent
+// (angle_turns), is wrapped by v_fract and rounded to a bin by one conversion, slot 36 being bin 0 again.
 #ifndef SIFTMI_ORI_WAVES
 #define SIFTMI_ORI_WAVES 7
 #endif
@@ -958,10 +977,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
             // one sample: central differences (dx, dy), not halved -- the gradient is (dx, dy) / 2 (SIFTGradient.metal:31-32): halving is
             // exact, so the angle atan2(tx, ty) is that of (dx, dy), and |gradient| = sqrt(dx^2 + dy^2) / 2 with the 1/2 in the unit
             auto accumulate = [&](float dx, float dy, float gi, float gj) {
-                const float bin = octant_bin36(dx, dy);                 // 36 atan2(tx, ty) / 2 pi taken into [0, 36]
+                const float mag = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, 1.0e-30f)));        // > 0 (angle_turns)
+                const float bin = __builtin_amdgcn_fractf(angle_turns(dx, dy, mag)) * (float)ORI_BINS;  // 36 atan2(tx, ty) / 2 pi taken into [0, 36)
                 int b;
                 asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(b) : "v"(bin));    // floor(bin + 0.5) = round(bin) for bin >= 0; 36 -> slot 36 = bin 0
-                const float m = (__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * gi) * gj;
+                const float m = (mag * gi) * gj;
 #if !(defined(SIFTMI_ORI_ABL) && SIFTMI_ORI_ABL == 1)
                 lds_add_bits(hist_lds + ((unsigned)b << 2), 0, m);
 #else
@@ -1180,18 +1200,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     // fall into the same cell and bin, and same-address lanes of one LDS add serialise.  The copies of a slot are INTERLEAVED (u32 index
     // = slot * NCOPY + copy, round 3): four neighbouring lanes that hit the same bin then touch four neighbouring banks.
     constexpr int NCOPY = SIFTMI_DESC_NCOPY;
-    constexpr int NSLOT = 10;                              // orientation slots per cell (see above)
+    constexpr int NSLOT = 9;                               // orientation slots per cell: bins 0 ... 7 and slot 8 = bin 0 again (the upper neighbour of 7)
     constexpr int HIST = 16 * NSLOT * NCOPY;               // u32 per histogram
     constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
     static_assert(WPB == 4 || (!COOP && WPB == 1), "COOP shares one descriptor among the four wavefronts of a workgroup");
-    // The address of a contribution is that of cell (fx, fy) with fx, fy >= -1 (a corner at -1 is reached through its neighbour at 0 by an
-    // immediate offset), i.e. up to 5 NSLOT slots below the histogram: PAD keeps that address non-negative for the first histogram too.
-    constexpr int PAD = 5 * NSLOT * NCOPY;
-    __shared__ unsigned hist_all[PAD + WPB * HIST];
-    __shared__ float gtab_all[WPB][MAXCOL + 4];            // exp(-k^2 / 8 hw^2) 2^-63 (2^-unit_shift folded in), k = -radius ... radius + 3
-    __shared__ short col_start_all[WPB][MAXCOL + 2];          // walk index of a row's first candidate (<= 128 * 128 / 1: fits 15 bits)
-    __shared__ short col_lo_all[WPB][MAXCOL];
-    __shared__ short col_len_all[WPB][MAXCOL];
+    // One LDS block: per wavefront {weight table, walk tables} first, the histograms after them.  The address of a contribution is that
+    // of cell (fx, fy) with fx, fy >= -1 (a corner at -1 is reached through its neighbour at 0 by an immediate offset), i.e. up to 5 NSLOT
+    // slots below its histogram: the tables in front keep that address non-negative for the first histogram too.
+    constexpr int QCAP = PATCH ? 0 : 832;                   // quads the walk's quad table holds (a window of the reference's schedule has <= 790)
+    constexpr int TAB_BYTES = (MAXCOL + 4) * 4 + QCAP * 2 + (MAXCOL + 2) * 2 + MAXCOL + (PATCH ? MAXCOL * 2 : 0);   // gtab, qtab, col_start, col_lo (i8), col_len
+    constexpr int PAD_BYTES = WPB * TAB_BYTES >= 5 * NSLOT * NCOPY * 4 ? 0 : 5 * NSLOT * NCOPY * 4 - WPB * TAB_BYTES;   // (the tables usually are the pad)
+    static_assert(TAB_BYTES % 4 == 0 && PAD_BYTES % 4 == 0, "u32 histograms behind the tables");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB * TAB_BYTES + PAD_BYTES + WPB * HIST * 4];
     constexpr int TP = 20;                                 // floats per staged tile row (18 used; 80 B keeps a quad's row segment 16-byte aligned)
     static_assert(!PATCH || !COOP, "PATCH: one wavefront per descriptor");
     __shared__ __attribute__((aligned(16))) float tile_all[PATCH ? WPB : 1][PATCH ? 18 * TP : 4];
@@ -1199,13 +1219,24 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     const int hw_ = COOP ? 0 : wv;                          // whose histogram copies: the workgroup's (COOP) or this wave's
     constexpr int STRIDE = COOP ? 256 : 64;                 // lanes walking one descriptor's samples
     const int lidx = COOP ? (int)threadIdx.x : lane;
-    unsigned *hist0 = hist_all + PAD + hw_ * HIST;
+    unsigned *hist0 = reinterpret_cast<unsigned *>(lds_raw + WPB * TAB_BYTES + PAD_BYTES) + hw_ * HIST;
     // byte address (LDS) of this lane's copy of slot 0, as a float: a contribution's address is formed in float (exact: < 2^24)
-    const float hist_base_f = (float)((unsigned)(size_t)(lds_u32_t *)hist0 + 4u * (unsigned)(lane & (NCOPY - 1)));
-    float *gtab = gtab_all[wv];
-    short *col_start = col_start_all[wv];
-    short *col_lo = col_lo_all[wv];
-    short *col_len = col_len_all[wv];
+    // Which quads a lane takes and which copy it adds to (round 6; the adds' LDS conflicts were 1.0 of the loop's 4.6 ms once the vector
+    // work had shrunk: profiles/desc_variants_r06.log).  An LDS add is served in two groups, lanes 0-31 and 32-63, and lanes of a group
+    // that hit one bank (or worse one address) take turns.  A trip's 64 quads are ~8 window rows of ~8 quads; with quad = lane, a group
+    // held four ADJACENT rows -- the same cells, mostly the same orientation bin -- and rows 8 quads long gave vertical neighbours the same
+    // copy (lane & 3).  Now the lanes of a group take alternate blocks of 8 quads (position p = lane with bits 3 and 5 swapped: rows
+    // 0, 2, 4, 6 against 1, 3, 5, 7), and the copy is (p & 1) -- horizontal neighbours -- with the block's index above it.
+    const int qpos = (lane & ~0x28) | ((lane & 8) << 2) | ((lane & 32) >> 2);
+    static_assert(NCOPY == 2 || NCOPY == 4 || NCOPY == 8, "copy = one column bit + block bits");
+    const int copy = (qpos & 1) | (((qpos >> 4) & (NCOPY / 2 - 1)) << 1);
+    const float hist_base_f = (float)((unsigned)(size_t)(lds_u32_t *)hist0 + 4u * (unsigned)copy);
+    unsigned char *tab = lds_raw + wv * TAB_BYTES;
+    float *gtab = reinterpret_cast<float *>(tab);                                        // exp(-k^2 / 8 hw^2) 2^-63 (2^-half_shift folded in), k = -radius ... radius + 3
+    unsigned short *qtab = reinterpret_cast<unsigned short *>(tab + (MAXCOL + 4) * 4);   // quad q of the walk: row | (j0 + radius) << 7
+    short *col_start = reinterpret_cast<short *>(tab + (MAXCOL + 4) * 4 + QCAP * 2);     // walk index of a row's first candidate (<= 128 * 128 / 1: fits 15 bits)
+    signed char *col_lo = reinterpret_cast<signed char *>(col_start + MAXCOL + 2);       // first candidate column of a row (|.| <= 63)
+    short *col_len = reinterpret_cast<short *>(col_lo + MAXCOL);                         // (PATCH only)
     const int group = group_index(P, blockIdx.y), frame = group / P.n_octaves, o = group - frame * P.n_octaves;
     const int n = min(desc_count[group], P.cap_desc[o]);
     const int w = P.w[o], h = P.h[o];
@@ -1235,6 +1266,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
         while (ldexpf(bound, -2 * half_shift) >= 240.0f) half_shift++;       // (wave-uniform; no trip with the reference's schedule)
         const float gscale = ldexpf(1.0f, -63 - half_shift);
         auto gauss = [&](int k) -> float { const float f = (float)k; return __builtin_amdgcn_exp2f(kg * (f * f)) * gscale; };
+        const float theta_turns = theta * 0.159154943091895336f;              // theta in [0, 2 pi)
 
         if (COOP) {
             __syncthreads();                                                          // wave 0 is done reading the previous descriptor's bins
@@ -1288,7 +1320,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 int incl = nun;                                            // inclusive wave prefix sum
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-                if (cidx < side) { col_start[cidx] = (short)(run + incl - nun); col_lo[cidx] = (short)lo; if (PATCH) col_len[cidx] = (short)len; }
+                const int start = run + incl - nun;
+                if (cidx < side) { col_start[cidx] = (short)start; col_lo[cidx] = (signed char)lo; if (PATCH) col_len[cidx] = (short)len; }
+                // the quads of an interior window, one entry each: the walk then finds a quad's row and first column by ONE read (round 5
+                // advanced through col_start row by row: ~8 dependent LDS reads and ~40 vector instructions per trip of 64 quads)
+                if (QCAP > 0 && unit == 4 && cidx < side)
+                    for (int k4 = 0; k4 < nun && start + k4 < QCAP; k4++) qtab[start + k4] = (unsigned short)(cidx | ((lo + radius + 4 * k4) << 7));
                 run += __shfl(incl, 63);
             }
             total = run;
@@ -1310,10 +1347,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
         auto sample = [&](auto interior_tag, float fj, int i, float gj, float gi, float t_xp, float t_xm, float t_yp, float t_ym) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
             const float fi = (float)i;
-            const float rx = fmaf(fj, cs, -(fi * sn));                     // (j cosT - i sinT) / histogramWidth
-            const float ry = fmaf(fj, sn, fi * cs);                        // (j sinT + i cosT) / histogramWidth
-            const float bx = rx + 1.5f, by = ry + 1.5f;                    // + d / 2 - 0.5: cell coordinates; the reference drops a sample
-                                                                           // unless both lie in (-1, 4) (addValue :66-68): the cell tests below
+            // cell coordinates (rx, ry) + d / 2 - 0.5 with (rx, ry) = the offset rotated by -theta, / histogramWidth; the reference drops a
+            // sample unless both lie in (-1, 4) (addValue :66-68): the cell tests below
+            const float bx = fmaf(fj, cs, fmaf(fi, -sn, 1.5f));
+            const float by = fmaf(fj, sn, fmaf(fi, cs, 1.5f));
             float dx, dy;                                                  // central differences, not yet halved
             if (INTERIOR) {
                 dx = t_xp - t_xm;
@@ -1331,13 +1368,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 }
                 dx = tx; dy = ty;
             }
-            // gradient (tx, ty) = (dx, dy) / 2 (SIFTGradient.metal:31-32), angle atan2(tx, ty), orientation = angle - theta: the
-            // vector (x = ty, y = tx) rotated by -theta; its direction does not depend on the factor 1/2
-            const float xr = fmaf(dy, cosT, dx * sinT), yr = fmaf(dx, cosT, -(dy * sinT));
-            const float bin = octant_bin(yr, xr);                          // in [0, 8]
-            // value = |gradient| exp(-(rx^2 + ry^2) / 8) 2^-126: |gradient| = sqrt(dx^2 + dy^2) / 2, so `v` is the value in units of
+            // gradient (tx, ty) = (dx, dy) / 2 (SIFTGradient.metal:31-32): its angle atan2(tx, ty) does not depend on the factor 1/2;
+            // orientation = angle - theta wrapped into [0, 2 pi), bin = 8 orientation / 2 pi (SIFTDescriptor.metal:203-213): in turns,
+            // the wrap is v_fract (which stays below 1: bin < 8)
+            const float mag = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, 1.0e-30f)));       // 2 |gradient|, > 0 (angle_turns)
+            const float bin = __builtin_amdgcn_fractf(angle_turns(dx, dy, mag) - theta_turns) * 8.0f;
+            // value = |gradient| exp(-(rx^2 + ry^2) / 8) 2^-126: |gradient| = mag / 2, so `v` is the value in units of
             // 2^-24 2^-149 -- at most sqrt(2) 2^-126, inside the range where a float's bits are linear in its value
-            const float v = (__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)) * gj) * gi;
+            const float v = (mag * gj) * gi;
             {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
                 // and bin wrap (:59-79); here one test per cell corner, and the upper orientation bin is the next slot.
                 // The "upper" corner is floor + 1 here, not ceil: they differ only when the coordinate is an integer, and then
@@ -1346,12 +1384,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 const float fx = __builtin_floorf(bx), fy = __builtin_floorf(by), fb = __builtin_floorf(bin);
                 const float iMax = bx - fx, iMin = 1.0f - iMax;
                 const float jMax = by - fy, jMin = 1.0f - jMax;
-                const float bMax = bin - fb, bMin = 1.0f - bMax;
                 // cell c in {0, 1, 2, 3} <=> bits(c) <= bits(3.0f): negative floors have the sign bit set, larger ones larger bits (the
                 // floor of a value in [0, 1) is +0)
                 const bool xa = __float_as_uint(fx) <= 0x40400000u, xb = __float_as_uint(fx + 1.0f) <= 0x40400000u;
                 const bool ya = __float_as_uint(fy) <= 0x40400000u, yb = __float_as_uint(fy + 1.0f) <= 0x40400000u;
-                const float va = bMin * v, vb = bMax * v;                  // the value's share of either orientation bin
+                // the value's share of either orientation bin.  Every factor below is >= +0, so is every product: a contribution's sign
+                // bit is never set (vb <= v as a rounded product of v and a factor < 1, so v - vb >= +0 too)
+                const float vb = (bin - fb) * v, va = v - vb;
                 // byte address of slot ((fy 4 + fx) NSLOT + fb), this lane's copy: exact in float (garbage where no test passes)
                 const float slot = fmaf(fy, (float)(4 * NSLOT), fmaf(fx, (float)NSLOT, fb));
                 unsigned a;
@@ -1429,7 +1468,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
             };
             auto gauss_at = [&](int k) -> float { return compact ? gtab[k + radius] : gauss(k); };   // (the table holds gauss(k): same bits)
             if constexpr (INTERIOR) {
-                if (lidx >= total) return;
                 if (compact) {
                     // quads: row y holds texels x - 1 ... x + 4 of the quad's four samples x ... x + 3 (b128 + b64), rows y - 1 and y + 1
                     // texels x ... x + 3 (b128 each).  The last quad of a row runs up to three candidates past its interval: their texels
@@ -1440,17 +1478,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                     // (measured equal or 1-2 % behind with the prefetch, profiles/desc_variants_r05.log).
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    for (int q = lidx; q < total; q += STRIDE) {
-                        while (q >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }
-                        const int i = cur - radius;
-                        const int j0 = (int)col_lo[cur] + ((q - cur_start) << 2);
+                    auto quad = [&](int row, int jidx) {                      // the four candidates jidx - radius ... + 3 of window row `row`
+                        const int i = row - radius, j0 = jidx - radius;
                         const int c = __mul24(ipy + i - 1, g.pitch) + ((ipx + j0 - 1) << 2);    // texel (x - 1, y - 1); both factors < 2^24
                         const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);
                         const u32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);
                         const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);
                         const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);
-                        const float gi = gtab[cur];
-                        const float *gq = gtab + (j0 + radius);
+                        const float gi = gtab[row];
+                        const float *gq = gtab + jidx;
                         const float G[4] = {gq[0], gq[1], gq[2], gq[3]};
                         const float fj0 = (float)j0;
                         const float A[6] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
@@ -1460,6 +1496,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
 #pragma unroll
                         for (int s4 = 0; s4 < 4; s4++)
                             sample(interior_tag, fj0 + (float)s4, i, G[s4], gi, A[s4 + 2], A[s4], D[s4], U[s4]);
+                    };
+                    if (QCAP > 0 && total <= QCAP) {
+                        for (int q = COOP ? wv * 64 + qpos : qpos; q < total; q += STRIDE) { const int e = qtab[q]; quad(e & 127, e >> 7); }
+                    } else {
+                        for (int q = lidx; q < total; q += STRIDE) {
+                            while (q >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }
+                            quad(cur, (int)col_lo[cur] + ((q - cur_start) << 2) + radius);
+                        }
                     }
                     return;
                 }
@@ -1469,6 +1513,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                     t_xp = layer_ld_s(g, c + 8, g.pitch); t_xm = layer_ld_s(g, c, g.pitch);
                     t_yp = layer_ld_s(g, c + 4, 2 * g.pitch); t_ym = layer_ld(g, c + 4);
                 };
+                if (lidx >= total) return;
                 int j, i;
                 float a0, a1, a2, a3;
                 locate(lidx, j, i);
@@ -1496,15 +1541,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
 #undef DESC_HADD
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
         __threadfence_block();
-        // features lane and lane + 64 (feature = cell * 8 + bin): the NCOPY copies of their slot, and for bin 0 those of slot 8 (the other
-        // bins read slot 9, which only ever received zeros).  Sums stay below 2^32 (header).
+        // features lane and lane + 64 (feature = cell * 8 + bin): the NCOPY copies of their slot, and for bin 0 those of slot 8.
+        // Sums stay below 2^32 (header).
         unsigned a0 = 0u, a1 = 0u;
         {
             const int cell = lane >> 3, b = lane & 7;
             const unsigned *s0 = hist0 + (cell * NSLOT + b) * NCOPY, *s1 = s0 + 8 * NSLOT * NCOPY;
-            const int alias = ((b == 0 ? 8 : 9) - b) * NCOPY;
 #pragma unroll
-            for (int c = 0; c < NCOPY; c++) { a0 += s0[c] + s0[alias + c]; a1 += s1[c] + s1[alias + c]; }
+            for (int c = 0; c < NCOPY; c++) { a0 += s0[c]; a1 += s1[c]; }
+            if (b == 0) {
+#pragma unroll
+                for (int c = 0; c < NCOPY; c++) { a0 += s0[8 * NCOPY + c]; a1 += s1[8 * NCOPY + c]; }
+            }
         }
         const float unit_scale = ldexpf(1.0f, -24 + 2 * half_shift);        // back to the reference's units (the normalisation removes it again)
         float f0 = (float)a0 * unit_scale, f1 = (float)a1 * unit_scale;
