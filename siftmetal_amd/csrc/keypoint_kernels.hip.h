@@ -708,135 +708,64 @@ __global__ __launch_bounds__(1024) void kp_row_sort_small_kernel(PyramidDesc P, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Histogram accumulation in 64-bit fixed point.  Measured on MI355X (tools/ubench/ubench_lds_atomic.hip):
-// the native LDS float atomic ds_add_f32 costs ~177 cycles per wave-instruction, ds_add_u64 ~6.  All
-// histogram contributions are non-negative and a bin total stays below 2^10 (<= ~1200 samples x
-// |gradient| <= 0.71), so fixed-point sums in u64 are order-independent (bit-reproducible) and closer to the
-// real-number sum than the reference's sequential f32 sum; the difference to the oracle is its own f32
-// rounding (~1e-6 relative), inside the stated tolerances.
-#ifndef SIFTMI_LEAN_ATAN
-#define SIFTMI_LEAN_ATAN 1
-#endif
-// (Rounds 1-2 accumulated value * 2^40: no f32 -> u64 instruction exists, so every contribution took two 32-bit conversions,
-// 6 VALU with the scaling.  A double add of 2^52 and a mantissa mask was 3 VALU but issued slower.)
-// The sample loops of the orientation and descriptor kernels accumulate in units of 2^-32.  A
-// contribution is value x weight <= 0.71 for pixel values in [0, 1] (|gradient| <= sqrt(2) / 2), so c * 2^32 fits ONE
-// v_cvt_u32_f32 (which saturates instead of wrapping for out-of-range float input) and the 64-bit add takes it zero-extended:
-// 2 VALU per contribution (fma with the +0.5 that makes the conversion round to nearest, convert) against 6 for the 2^40 form
-// -- the descriptor loop converts 8 values per sample.  Resolution 2.3e-10 per contribution, unbiased: a bin of a few hundred
-// contributions carries ~2e-9 of absolute error against bin totals of 0.01 ... 30, still two orders below the f32 sums of
-// the reference.  Bin totals stay below 2^10, i.e. 2^42 here.
-// The conversion is the hardware instruction itself (v_cvt_u32_f32 saturates out-of-range and negative inputs and maps NaN to 0),
-// not a C++ float -> unsigned cast, which is undefined out of range: a frame that breaks the [0, 1] input contract (SIFTMI_FMT_GRAYF32,
-// reported by check_unit_range_kernel) then gives saturated histograms, not poison.
-__device__ __forceinline__ unsigned long long fix32_product(float p, float v32) {
-    unsigned r;
-    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(fmaf(p, v32, 0.5f)));
-    return (unsigned long long)r;
-}
-__device__ __forceinline__ float from_fix32(unsigned long long v) { return (float)v * 2.3283064365386963e-10f; }
-// Round 6: the sample loops add the BITS of a denormal-range float (descriptor_kernel's header) to u32 bins
+// Histogram accumulation: order-free integer sums in LDS.  Measured on MI355X (tools/ubench/ubench_lds_atomic.hip, ubench_mix.hip):
+// the native LDS float atomic ds_add_f32 costs ~177 cycles per wave-instruction, ds_add_u64 ~6, ds_add_u32 ~4.  All histogram
+// contributions are non-negative, so fixed-point sums are order-independent (bit-reproducible: every launch form gives the same bytes).
+// Rounds 1-5 accumulated value x 2^32 in u64 bins (fma + v_cvt_u32_f32 per contribution).  Round 6 accumulates value x 2^24 in u32
+// bins and takes the integer from the BITS of a denormal-range float product -- see descriptor_kernel's header; resolution 6e-8 per
+// contribution in the reference's units against its own sequential f32 sums' ~1e-6 relative.
 typedef __attribute__((address_space(3))) unsigned lds_u32_t;
 __device__ __forceinline__ void lds_add_bits(unsigned byte_addr, int u32_offset, float contribution) {
     lds_u32_t *p = (lds_u32_t *)(size_t)byte_addr;
     __hip_atomic_fetch_add(p + u32_offset, __float_as_uint(contribution), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// atan2(y, x) of finite arguments for the sample loops (their VALU count is the limit of the orientation and descriptor
-// kernels; the library atan2f is 38 of it, with exponent juggling for a correctly scaled quotient and inf / nan cases that
-// cannot occur here).  Octant reduction, quotient by v_rcp_f32 (1 ulp), odd degree-17 polynomial fitted by
-// tools/fit_atan.py: 2.4 ulp / 2.9e-7 rad worst case over 2M random arguments.  An angle error of that size moves 1e-7 of
-// a sample's weight between neighbouring bins of the descriptor, and one sample in ~3e5 to the neighbouring orientation
-// bin -- two orders below the differences the f32 sums of the reference carry anyway.  atan2_lean(0, 0) = 0 as atan2f.
-__device__ __forceinline__ float atan2_lean(float y, float x) {
-#if SIFTMI_LEAN_ATAN
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
-    const float s = t * t;
-    float q = 2.622172935e-03f;
-    q = fmaf(q, s, -1.513224095e-02f);
-    q = fmaf(q, s, 4.112136364e-02f);
-    q = fmaf(q, s, -7.366662472e-02f);
-    q = fmaf(q, s, 1.057391018e-01f);
-    q = fmaf(q, s, -1.418596953e-01f);
-    q = fmaf(q, s, 1.999039650e-01f);
-    q = fmaf(q, s, -3.333298564e-01f);
-    float r = fmaf(t, s * q, t);
-    r = ay > ax ? 1.57079632679489662f - r : r;
-    r = x < 0.0f ? 3.14159265358979324f - r : r;
-    return copysignf(r, y);
-#else
-    return atan2f(y, x);
-#endif
-}
-
-// Descriptor orientation bin of a gradient that has already been rotated into the keypoint's frame: 8 atan2(y, x) / 2 pi taken
-// into [0, 8].  The reference computes atan2 of the raw gradient, subtracts theta, wraps with two while loops and scales
-// (SIFTDescriptor.metal:203-213); rotating the two gradient components by -theta first (4 VALU) gives the same angle and lets
-// the octant reduction of atan2_lean deliver the BIN directly: the polynomial's coefficients carry the factor 4 / pi, the three
-// reflections are exact (2 - r, 4 - r, 8 - r), and the subtraction, both wrap loops and the scaling disappear (~38 -> ~29
-// VALU).  The angle differs from the reference's by the rounding of the rotation (~1e-7 rad): the trilinear weights are
-// continuous in the bin, so that moves 1e-7 of a sample's weight between neighbouring bins.  octant_bin(0, 0) = 0.
-__device__ __forceinline__ float octant_bin(float y, float x) {
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
-    const float s = t * t;
-    // Round 6: six coefficients instead of eight (tools/fit_atan.py 6, x 4 / pi): 8.8e-7 of a bin worst case (6.2e-7 rad; the eight-term
-    // fit reached the float floor, 2.9e-7 rad).  A bin error e moves e of a sample's weight to the neighbouring orientation bin; the
-    // descriptor's stated tolerance is 1e-4 (L2 of the unit vector), the measured effect is in profiles/desc_margin_r06.log.
-    float q = 9.388612583e-03f;
-    q = fmaf(q, s, -4.522449896e-02f);
-    q = fmaf(q, s, 1.046182811e-01f);
-    q = fmaf(q, s, -1.705982834e-01f);
-    q = fmaf(q, s, 2.528888583e-01f);
-    q = fmaf(q, s, -4.243120849e-01f);
-    float r = t * fmaf(s, q, 1.27323954473516268f);        // 4 / pi atan(t), in [0, 1]
-    r = ay > ax ? 2.0f - r : r;
-    r = x < 0.0f ? 4.0f - r : r;
-    return y < 0.0f ? 8.0f - r : r;
-}
-// The same in units of 10 degrees (the 36 bins of the orientation histogram), in [0, 36]: coefficients x 18 / pi.
-__device__ __forceinline__ float octant_bin36(float y, float x) {
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
-    const float s = t * t;
-    float q = 4.224875569e-02f;
-    q = fmaf(q, s, -2.035102397e-01f);
-    q = fmaf(q, s, 4.707822502e-01f);
-    q = fmaf(q, s, -7.676922679e-01f);
-    q = fmaf(q, s, 1.137999892e+00f);
-    q = fmaf(q, s, -1.909404397e+00f);
-    float r = t * fmaf(s, q, 5.72957795130823209f);        // 18 / pi atan(t), in [0, 4.5]
-    r = ay > ax ? 9.0f - r : r;
-    r = x < 0.0f ? 18.0f - r : r;
-    return y < 0.0f ? 36.0f - r : r;
-}
-
 // Round 6: atan2(y, x) / 2 pi in (-0.5, 0.5] by the half-angle tangent.  With m = |(x, y)| (which both sample loops need anyway):
 // tan(a / 2) = y / (m + x); taking |x| folds the angle into [-pi/2, pi/2] (|t| <= 1, sign of y kept, no octant swap: no min / max), and
-// x < 0 reflects it, pi - a' for either sign of y.  Same six-term polynomial (here / pi: atan(t) / pi = a' / 2 pi); 1.2e-6 rad worst
-// case (tools/fit_atan.py; the argument of atan is half the angle, so the fit's error doubles).  Against octant_bin: one reflection
-// instead of three, no v_max3 / v_min -- ~8 ns of ~45 per sample at the measured issue costs (profiles/ubench_mix_r06.log).
+// x < 0 reflects it, pi - a' for either sign of y.  Six-term odd polynomial (here / pi: atan(t) / pi = a' / 2 pi); 1.2e-6 rad worst
+// case (tools/fit_atan.py 6 pin; the argument of atan is half the angle, so the fit's error doubles).  Rounds 2-5 reduced to an octant
+// (min / max of |x|, |y|, three reflections, eight terms: 2.9e-7 rad): this form has one reflection and no v_max3 / v_min -- ~8 ns of
+// ~45 per sample at the measured issue costs (profiles/ubench_mix_r06.log).  An angle error e moves e x 8 / 2 pi of a sample's weight to
+// the neighbouring orientation bin of the descriptor, and one sample in ~1e5 to the neighbouring bin of the orientation histogram.
 // m must be > 0 (the callers add 1e-30 under the root: a normal number -- v_sqrt_f32 flushes denormal inputs), so (0, 0) gives 0 like atan2f.
 __device__ __forceinline__ float angle_turns(float y, float x, float m) {
     const float t = y * __builtin_amdgcn_rcpf(m + fabsf(x));
     const float s = t * t;
-    float q = 2.347153146e-03f;
-    q = fmaf(q, s, -1.130612474e-02f);
-    q = fmaf(q, s, 2.615457028e-02f);
-    q = fmaf(q, s, -4.264957085e-02f);
-    q = fmaf(q, s, 6.322221458e-02f);
-    q = fmaf(q, s, -1.060780212e-01f);
+    float q = 2.410817426e-03f;                           // (the fit is pinned at t = tan(pi / 8): angle_bins36)
+    q = fmaf(q, s, -1.149140950e-02f);
+    q = fmaf(q, s, 2.634806186e-02f);
+    q = fmaf(q, s, -4.273251072e-02f);
+    q = fmaf(q, s, 6.323227286e-02f);
+    q = fmaf(q, s, -1.060769856e-01f);
     const float r = t * fmaf(s, q, 0.318309886183790672f);
     return x < 0.0f ? 0.5f - r : r;
 }
 
+// |atan2(y, x)| in units of 10 degrees (the 36 bins of the orientation histogram), in [0, 18], for y >= 0: the same with the coefficients x 36.
+__device__ __forceinline__ float angle_bins36(float y_abs, float x, float m) {
+    const float t = y_abs * __builtin_amdgcn_rcpf(m + fabsf(x));
+    const float s = t * t;
+    float q = 8.678942919e-02f;
+    q = fmaf(q, s, -4.136907160e-01f);
+    q = fmaf(q, s, 9.485301971e-01f);
+    q = fmaf(q, s, -1.538370371e+00f);
+    q = fmaf(q, s, 2.276361704e+00f);
+    q = fmaf(q, s, -3.818771601e+00f);
+    // Ties.  The only bin boundaries that gradients of pixel differences hit EXACTLY are 4.5 and 13.5 (|dx| == |dy|), and exactly
+    // symmetric images (checkerboards, 8-bit synthetic patterns) put a large share of their samples on or within an ulp of them.  In the
+    // reference's own f32 expression, round(36 (angle / 2 pi)), pi/4 gives 4.4999995 -> 4 and 3 pi/4 gives 13.5 -> 14.  So the
+    // polynomial fit is PINNED at t = tan(pi / 8) (tools/fit_atan.py 6 pin: zero fit error there, 4.05e-7 rad elsewhere; the f32
+    // evaluation returns 4.5 -5e-7 / +1e-6 for an exact diagonal), and 1e-6 is taken off the acute angle before the reflection (free: the
+    // last multiply becomes an fma), which puts both ties on the reference's side -- emulated against the reference's expression on
+    // 2 M gradients within 3e-6 of the diagonal (same script): 24 of 200 k exact diagonals and 2.7 % of the others fall on the other
+    // side, against every exact diagonal without it.  Every other bin boundary moves by 1.7e-7 rad, inside this function's own error.
+    const float r = fmaf(t, fmaf(s, q, 11.4591559026164642f), -1.0e-6f);
+    return x < 0.0f ? 18.0f - r : r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gradient on demand: SIFTGradient.metal:15-39 (atan2(tx, ty) -- argument order as in the
-// reference -- and |grad| of central differences, mirror edges); outside the image -> (0, 0).
+// reference -- and |grad| of central differences, mirror edges; outside the image -> (0, 0)) is evaluated inside the two sample loops.
 //
 // The layer is addressed through a buffer resource: one keypoint per wavefront, so the layer base is wave-uniform and sits
 // in SGPRs; a sample then needs one 32-bit byte offset (2 VALU) instead of four 64-bit addresses (the orientation and
@@ -863,29 +792,6 @@ __device__ __forceinline__ float layer_ld(const LayerView &v, int byte_off) {
 __device__ __forceinline__ float layer_ld_s(const LayerView &v, int byte_off, int sgpr_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(v.rsrc, byte_off, sgpr_off, 0));
 }
-template <bool FAST_SQRT = false>
-__device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, float &theta, float &mag) {
-    float tx = 0.0f, ty = 0.0f;
-    if ((unsigned)(gx - 1) < (unsigned)(v.w - 2) && (unsigned)(gy - 1) < (unsigned)(v.h - 2)) {          // interior: no mirror
-        const int c = gy * v.pitch + (gx << 2);
-        tx = (layer_ld(v, c + 4) - layer_ld(v, c - 4)) * 0.5f;
-        ty = (layer_ld(v, c + v.pitch) - layer_ld(v, c - v.pitch)) * 0.5f;
-    } else if (gx >= 0 && gy >= 0 && gx < v.w && gy < v.h) {
-        const int w = v.w, h = v.h;
-        const float *g = v.g;
-        const int px = symm(gx + 1, w), mx = symm(gx - 1, w);
-        const int py = symm(gy + 1, h), my = symm(gy - 1, h);
-        auto rd = [&](int x, int y) -> float { return (x < 0 || y < 0 || x >= w || y >= h) ? 0.0f : g[(size_t)y * w + x]; };
-        tx = (rd(px, gy) - rd(mx, gy)) * 0.5f;
-        ty = (rd(gx, py) - rd(gx, my)) * 0.5f;
-    } else {                                                            // outside the image -> (0, 0)
-        theta = 0.0f; mag = 0.0f;
-        return;
-    }
-    theta = atan2_lean(tx, ty);
-    mag = FAST_SQRT ? __builtin_amdgcn_sqrtf(tx * tx + ty * ty) : sqrtf(tx * tx + ty * ty);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Orientation: SIFTOctave.getKeypointOrientations (SIFTOctave.swift:290-382) + SIFTOrientation.metal.
 // One wavefront per keypoint; the (2r+1)^2 window is strided over the 64 lanes into a 36-bin LDS
@@ -897,8 +803,8 @@ __device__ __forceinline__ void gradient_at(const LayerView &v, int gx, int gy, 
 // WPB: wavefronts per workgroup (COOP = false), see descriptor_kernel
 // Round 6 (as the descriptor's sample loop; costs in profiles/ubench_mix_r06.log): contributions are denormal floats whose bits go to a u32
 // LDS add (24 fractional bits); the Gaussian weight exp(-(i^2 + j^2) / 2 lambda^2 sigma^2) is the product of two entries of a per-keypoint
-// table (zero past the window: the padding of a row's last quad needs no mask); the angle comes in turns from the half-angle tangent
-// (angle_turns), is wrapped by v_fract and rounded to a bin by one conversion, slot 36 being bin 0 again.
+// table (zero past the window: the padding of a row's last quad needs no mask); the angle's magnitude comes in units of 10 degrees from
+// the half-angle tangent (angle_bins36), is rounded to a bin by one conversion and reflected for a negative angle, slot 36 being bin 0 again.
 #ifndef SIFTMI_ORI_WAVES
 #define SIFTMI_ORI_WAVES 7
 #endif
@@ -978,9 +884,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
             // exact, so the angle atan2(tx, ty) is that of (dx, dy), and |gradient| = sqrt(dx^2 + dy^2) / 2 with the 1/2 in the unit
             auto accumulate = [&](float dx, float dy, float gi, float gj) {
                 const float mag = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, 1.0e-30f)));        // > 0 (angle_turns)
-                const float bin = __builtin_amdgcn_fractf(angle_turns(dx, dy, mag)) * (float)ORI_BINS;  // 36 atan2(tx, ty) / 2 pi taken into [0, 36)
-                int b;
-                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(b) : "v"(bin));    // floor(bin + 0.5) = round(bin) for bin >= 0; 36 -> slot 36 = bin 0
+                // bin = round(36 atan2(tx, ty) / 2 pi), negative + 36 (SIFTOrientation.metal:122-129).  round() is half away from zero, i.e.
+                // symmetric in the sign of the angle, which is the sign of tx: round the MAGNITUDE (floor(|.| + 0.5), one conversion) and
+                // reflect, 36 - q, for tx < 0 -- exactly diagonal gradients (8-bit synthetic images are full of them) then fall to the same
+                // side as in the reference whatever their quadrant.  q = 0 reflects to slot 36 = bin 0 again.
+                int q;
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(angle_bins36(fabsf(dx), dy, mag)));
+                const int b = dx < 0.0f ? ORI_BINS - q : q;
                 const float m = (mag * gi) * gj;
 #if !(defined(SIFTMI_ORI_ABL) && SIFTMI_ORI_ABL == 1)
                 lds_add_bits(hist_lds + ((unsigned)b << 2), 0, m);
@@ -1133,16 +1043,27 @@ __global__ __launch_bounds__(256) void desc_derive_kernel(PyramidDesc P, DetectP
 // ------------------------------------------------------------------------------------------------
 // Descriptor: SIFTOctave.getDescriptors (SIFTOctave.swift:384-492) + SIFTDescriptor.metal:15-237.
 // One wavefront per (keypoint, theta); the (2R+1)^2 rotated window is strided over the lanes and
-// scattered trilinearly into a 4x4x8 LDS histogram (u64 fixed point, see fix32_product); the two L2
+// scattered trilinearly into a 4x4x8 LDS histogram (integer sums, see lds_add_bits); the two L2
 // normalisations are wave reductions.  Samples whose truncated coordinate leaves the image contribute nothing (the
 // reference's behaviour there is undefined).
-// Float note.  Per sample the reference divides by histogramWidth twice, calls exp and sqrt.  Metal compiles those with
+// Float note.  Per sample the reference divides by histogramWidth twice, calls exp, sqrt and atan2.  Metal compiles those with
 // fast math (reciprocal multiply, native exp / sqrt, ~1-2 ulp); here: one IEEE reciprocal per descriptor and a multiply
-// per sample, v_exp_f32 (__expf) and v_sqrt_f32 -- 1-2 ulp on quantities that only weight a sample, against a stated
-// descriptor tolerance of 1e-4 (L2).  Measured against the oracle (IEEE division, glibc expf / sqrtf) on 17.6 k dense
-// descriptors: max L2 5.1e-7 with either form, 9 instead of 5 of 2.25 M quantised bins differ by 1
-// (tools/desc_margin.py); the sample loop is VALU-bound and this removes ~50 of its ~330 instructions.  The angle comes
-// from atan2_lean (above; 2.4 ulp): with it 11 of the 2.25 M bins differ, max L2 5.2e-7.
+// per sample, v_exp_f32 (table entries) and v_sqrt_f32 -- 1-2 ulp on quantities that only weight a sample -- and angle_turns
+// (1.2e-6 rad), against a stated descriptor tolerance of 1e-4 (L2 of the unit vector).  Measured against the oracle (IEEE division,
+// glibc expf / sqrtf / atan2f) on 17.6 k dense descriptors (tools/desc_margin.py, profiles/desc_margin_r06.log): max L2 3.4e-6 (4.6e-6 on
+// the sparse fields), 100 of 2.25 M quantised bins differ by 1.  Rounds 2-5 (2^-32 fixed point, 2.4-ulp atan2): 5.8e-7 / 11 bins, at
+// 5.5 instead of 4.2 ms per 1.13 M descriptors: the round-6 forms spend 6 of the tolerance's 170x margin.
+// inclusive prefix sum over the 64 lanes by DPP adds (row_shr 1 / 2 / 4 / 8 inside each row of 16, then row_bcast15 / row_bcast31 carry the
+// row totals up): six full-rate vector adds.  (__shfl_up goes through the LDS crossbar: six ds_bpermute + wait + select + add.)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -1208,9 +1129,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     // of cell (fx, fy) with fx, fy >= -1 (a corner at -1 is reached through its neighbour at 0 by an immediate offset), i.e. up to 5 NSLOT
     // slots below its histogram: the tables in front keep that address non-negative for the first histogram too.
     constexpr int QCAP = PATCH ? 0 : 832;                   // quads the walk's quad table holds (a window of the reference's schedule has <= 790)
-    constexpr int TAB_BYTES = (MAXCOL + 4) * 4 + QCAP * 2 + (MAXCOL + 2) * 2 + MAXCOL + (PATCH ? MAXCOL * 2 : 0);   // gtab, qtab, col_start, col_lo (i8), col_len
+    constexpr int TAB_BYTES = ((MAXCOL + 4) * 4 + QCAP * 2 + (MAXCOL + 2) * 2 + MAXCOL + (PATCH ? MAXCOL * 2 : 0) + 15) & ~15;   // gtab, qtab, col_start, col_lo (i8), col_len
     constexpr int PAD_BYTES = WPB * TAB_BYTES >= 5 * NSLOT * NCOPY * 4 ? 0 : 5 * NSLOT * NCOPY * 4 - WPB * TAB_BYTES;   // (the tables usually are the pad)
-    static_assert(TAB_BYTES % 4 == 0 && PAD_BYTES % 4 == 0, "u32 histograms behind the tables");
+    static_assert(TAB_BYTES % 16 == 0 && PAD_BYTES % 16 == 0 && HIST % 4 == 0, "16-byte aligned histograms behind the tables (cleared by 16-byte stores)");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB * TAB_BYTES + PAD_BYTES + WPB * HIST * 4];
     constexpr int TP = 20;                                 // floats per staged tile row (18 used; 80 B keeps a quad's row segment 16-byte aligned)
     static_assert(!PATCH || !COOP, "PATCH: one wavefront per descriptor");
@@ -1270,9 +1191,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
 
         if (COOP) {
             __syncthreads();                                                          // wave 0 is done reading the previous descriptor's bins
-            for (int c = threadIdx.x; c < HIST; c += 256) hist0[c] = 0u;
+            for (int c = threadIdx.x; c < HIST / 4; c += 256) reinterpret_cast<uint4 *>(hist0)[c] = make_uint4(0u, 0u, 0u, 0u);
         } else {
-            for (int c = lane; c < HIST; c += 64) hist0[c] = 0u;                          // all copies (contiguous)
+            for (int c = lane; c < HIST / 4; c += 64) reinterpret_cast<uint4 *>(hist0)[c] = make_uint4(0u, 0u, 0u, 0u);   // all copies (contiguous)
         }
         if (compact) for (int k = lane; k < side + 3; k += 64) gtab[k] = gauss(k - radius);
 
@@ -1317,16 +1238,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 }
                 const int len = max(hi - lo + 1, 0);
                 const int nun = unit == 4 ? (len + 3) >> 2 : len;          // walk indices of this row
-                int incl = nun;                                            // inclusive wave prefix sum
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                const int incl = wave_inclusive_scan(nun);
                 const int start = run + incl - nun;
                 if (cidx < side) { col_start[cidx] = (short)start; col_lo[cidx] = (signed char)lo; if (PATCH) col_len[cidx] = (short)len; }
                 // the quads of an interior window, one entry each: the walk then finds a quad's row and first column by ONE read (round 5
                 // advanced through col_start row by row: ~8 dependent LDS reads and ~40 vector instructions per trip of 64 quads)
                 if (QCAP > 0 && unit == 4 && cidx < side)
                     for (int k4 = 0; k4 < nun && start + k4 < QCAP; k4++) qtab[start + k4] = (unsigned short)(cidx | ((lo + radius + 4 * k4) << 7));
-                run += __shfl(incl, 63);
+                run += __builtin_amdgcn_readlane(incl, 63);
             }
             total = run;
             if (lane == 0) col_start[side] = (short)total;
@@ -1450,12 +1369,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 return;
             }
             int cur = 0;                                                   // window row of this lane's current sample
-            if (compact && lidx < total) {                                 // binary search once, then only advance
+            const bool by_table = INTERIOR && QCAP > 0 && compact && total <= QCAP;   // the quad table gives the row: nothing to search
+            if (compact && lidx < total && !by_table) {                    // binary search once, then only advance
                 int lo_c = 0, hi_c = side - 1;                             // last row whose start <= lidx
                 while (lo_c < hi_c) { const int mid = (lo_c + hi_c + 1) >> 1; if (col_start[mid] <= lidx) lo_c = mid; else hi_c = mid - 1; }
                 cur = lo_c;
             }
-            int cur_start = compact ? col_start[cur] : 0, next_start = compact ? col_start[cur + 1] : 0;
+            int cur_start = (compact && !by_table) ? col_start[cur] : 0, next_start = (compact && !by_table) ? col_start[cur + 1] : 0;
             auto locate = [&](int idx, int &j, int &i) {                   // j: x offset (inner), i: y offset (outer); idx never decreases
                 if (compact) {
                     while (idx >= next_start) { cur++; cur_start = next_start; next_start = col_start[cur + 1]; }   // empty rows have equal starts
@@ -1497,7 +1417,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                         for (int s4 = 0; s4 < 4; s4++)
                             sample(interior_tag, fj0 + (float)s4, i, G[s4], gi, A[s4 + 2], A[s4], D[s4], U[s4]);
                     };
-                    if (QCAP > 0 && total <= QCAP) {
+                    if (by_table) {
                         for (int q = COOP ? wv * 64 + qpos : qpos; q < total; q += STRIDE) { const int e = qtab[q]; quad(e & 127, e >> 7); }
                     } else {
                         for (int q = lidx; q < total; q += STRIDE) {

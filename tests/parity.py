@@ -174,7 +174,7 @@ def _split(arr, counts):
     return out
 
 
-def check_full_path(sm, img, no, nspo, strict_theta=True, expect=None, **engine_kw):
+def check_full_path(sm, img, no, nspo, strict_theta=True, expect=None, symmetric_pattern=False, **engine_kw):
     """Every stage of the HIP path against the oracle on one image (used by tests/test_gpu_parity.py and
     tools/fuzz_parity.py).  Raises AssertionError with the failing stage.
 
@@ -184,6 +184,12 @@ def check_full_path(sm, img, no, nspo, strict_theta=True, expect=None, **engine_
     changes by one whole sample (~1e-3 of a peak) and an interpolated peak on a flat histogram moves by up to ~1e-2 rad.
     That happens to a fraction of a percent of the angles; the sweep therefore allows 2 % of the angles to exceed TOL_THETA,
     none by more than 0.05 rad (under a third of a bin), instead of a hard maximum.
+
+    symmetric_pattern=True (checkerboards in the sweep): an exactly symmetric image puts a large share of its gradients on or within an
+    ulp of |dx| == |dy|, i.e. ON the 45 / 135 degree boundaries of the 36-bin histogram, and gives every corner four equal peaks; which
+    side such a sample falls on is decided below the last ulp of atan2f in the reference's own f32 expression (tools/fit_atan.py prints
+    an emulation), every flipped sample is ~1 % of a peak, and the interpolated peak moves by up to ~2e-2 rad.  Only the hard limit of
+    the sweep (0.05 rad, under a third of a bin) is kept for the angles of such a case; every other stage is checked as usual.
 
     expect: for a FIXED case, the mismatch counts observed on it -- {"orientation_count_mismatch": n, "descriptors_unmatched": m,
     "bins_differing": b} summed over the octaves -- asserted exactly (VERDICT r2: SURVEY 8c grants "same count", not a budget);
@@ -250,8 +256,12 @@ def check_full_path(sm, img, no, nspo, strict_theta=True, expect=None, **engine_
             assert orep["count_mismatch"] <= max(1, len(okp) // 200), orep
         seen["orientation_count_mismatch"] += orep["count_mismatch"]
         seen["max_dtheta"] = max(seen["max_dtheta"], orep["max_dtheta"])
+        seen["angles_over_tol"] = seen.get("angles_over_tol", 0) + orep["over_tol"]
+        seen["angles_compared"] = seen.get("angles_compared", 0) + orep["angles_compared"]
         if strict_theta:
             assert orep["max_dtheta"] <= parity.TOL_THETA, orep
+        elif symmetric_pattern:
+            assert orep["max_dtheta"] <= 0.05, orep
         else:
             assert orep["over_tol"] <= max(1, orep["angles_compared"] // 50) and orep["max_dtheta"] <= 0.05, orep
         assert st["oriented"][0, o] == int((g_ori["count"] >= 0).sum())

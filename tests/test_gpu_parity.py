@@ -67,6 +67,47 @@ def test_full_path_vs_oracle(sm, butterfly_bgra, name, size, no, nspo, mode):
     parity.check_full_path(sm, img, no, nspo, expect=EXACT_COUNTS, **MODES[mode])
 
 
+# A fixed-seed slice of the randomised sweeps (tests/sweep.py; tools/fuzz_parity.py / fuzz_api.py run them at any length): cases nobody
+# tuned a kernel against -- random sizes incl. odd ones and thin strips, 1-7 octaves, 3-7 scales per octave (2 needs a 37-tap layer: the
+# reference's ConvolutionParameters holds 32 and the library reports it, test_errors_and_capacity), gray-8 / gray-f32 / BGRA8
+# input, noise / checkerboards / constants / steps beside the blob fields, every blur + extrema launch form.  Single 1-2 Mpixel frames
+# are left to the tool (their oracle run takes most of a minute each); the fixed 1080p / 4096^2 cases below cover those launch shapes.
+SWEEP_SEED, SWEEP_CASES = 20261016, 24     # (seed picked for coverage before any run: all 8 image kinds, nspo 3-7, 1-7 octaves, 4 launch forms)
+_sweep_cache = {}
+
+
+def _sweep_case(index):
+    from tests import sweep
+    if "cases" not in _sweep_cache:
+        _sweep_cache["cases"] = sweep.parity_cases(SWEEP_SEED, SWEEP_CASES, nspo_choices=(3, 3, 4, 5, 6, 7), large=False)
+    return _sweep_cache["cases"][index]
+
+
+@pytest.mark.parametrize("index", range(SWEEP_CASES))
+def test_seeded_parity_sweep(sm, index, capsys):
+    from tests import sweep
+    c = _sweep_case(index)
+    r = sweep.run_parity_case(sm, c)
+    with capsys.disabled():
+        # the allowance of the sweep (strict_theta=False: 2 % of a case's angles may pass TOL_THETA, none by more than 0.05 rad -- only the
+        # latter on exactly symmetric patterns; bins_allowed rounds 0.1 % up to one bin below 1000 bins), and how far this case went into it
+        print("\n  sweep case %d: %s -> %s" % (index, sweep.describe_case(c),
+              {k: (float("%.3g" % v) if isinstance(v, float) else v) for k, v in r.items()}), end="")
+    assert r["max_l2_float"] <= parity.TOL_DESC_L2 and r["matched"] >= 0.995 * r["keypoints"] - 1
+
+
+def test_seeded_api_sweep(sm, capsys):
+    """36 random API operations on long-lived contexts (host batches, device-resident graph replays, single-frame calls, the three
+    matchers) at three frame sizes: every result equals a fresh lock-step-1 context's bit for bit."""
+    from tests import sweep
+    lines = []
+    fails = sweep.api_sweep(sm, 36, SWEEP_SEED, log=lines.append)
+    if fails:
+        with capsys.disabled():
+            print("\n".join(lines))
+    assert fails == 0, [l for l in lines if l.startswith("FAIL")]
+
+
 def test_butterfly_against_ipol_fixtures(sm, butterfly_bgra, ipol):
     """The reference's own golden data, checked directly on the HIP output."""
     eng = sm.Engine(512, 340, n_octaves=7)

@@ -1,13 +1,13 @@
-"""Randomised API-sequence sweep: one long-lived context driven through random sequences of host batches, device-resident
-(hipGraph-replayed) batches, single-frame detect + describe and matcher calls, with every result compared bit for bit with
-per-frame results from a fresh lock-step-1 context.  Catches state leaking between calls (stale counters, graph replays,
-stream ordering).  Run on the GPU box:  python tools/fuzz_api.py [n_ops] [seed]"""
+"""Randomised API-sequence sweep of any length and seed (tests/sweep.py::api_sweep: one long-lived context driven through random sequences
+of host batches, device-resident (hipGraph-replayed) batches, single-frame detect + describe and matcher calls, every result compared bit
+for bit with per-frame results from a fresh lock-step-1 context).  Catches state leaking between calls (stale counters, graph replays,
+stream ordering).  A fixed-seed slice runs inside `pytest -m gpu` (tests/test_gpu_parity.py::test_seeded_api_sweep).
+Run on the GPU box:  python tools/fuzz_api.py [n_ops] [seed] [--torch]"""
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 
 if "--torch" in sys.argv:            # torch first: the process then runs on the HIP runtime torch bundles (ROCm 7.0 build)
     sys.argv.remove("--torch")
@@ -15,119 +15,14 @@ if "--torch" in sys.argv:            # torch first: the process then runs on the
     torch.cuda.init()
 
 import siftmetal_amd as sm
-from siftmetal_amd import stream as smstream
-from tests.synth import blob_frame
-from oracle import pyoracle
+from tests import sweep
 
 
 def main():
     n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    rng = np.random.default_rng(seed)
-    fails = 0
     t0 = time.time()
-    for round_ in range(3):
-        w, h = [(640, 480), (1280, 960), (1920, 1080)][round_]
-        n_oct = int(rng.integers(2, 5))
-        B = int(rng.choice([1, 2, 3, 4, 8]))
-        pool = [blob_frame(w, h, 100 * round_ + i, n_blobs=int(rng.integers(20, 400))) for i in range(6)]
-        ref_eng = sm.Engine(w, h, n_octaves=n_oct, max_batch=1)
-        ref = []
-        for f in pool:
-            k, kc, d, dc = ref_eng.detect_describe_batch(f[None])
-            ref.append((k, kc[0], d, dc[0]))
-        ref_eng.close()
-        eng = sm.Engine(w, h, n_octaves=n_oct, max_batch=B)
-        streams = {}
-
-        def expect(ids):
-            return (np.concatenate([ref[i][0] for i in ids]), np.stack([ref[i][1] for i in ids]),
-                    np.concatenate([ref[i][2] for i in ids]), np.stack([ref[i][3] for i in ids]))
-
-        def check(tag, got, ids):
-            nonlocal fails
-            ek, ekc, ed, edc = expect(ids)
-            ok = (np.array_equal(got[1], ekc) and np.array_equal(got[3], edc) and got[0].tobytes() == ek.tobytes()
-                  and got[2].tobytes() == ed.tobytes())
-            print("%s %dx%d oct %d B %d: %s frames %s" % ("ok  " if ok else "FAIL", w, h, n_oct, B, tag, ids), flush=True)
-            fails += 0 if ok else 1
-
-        for op in range(n_ops // 3):
-            kind = rng.choice(["host", "device", "device", "single", "match", "approx", "geometry"])
-            ids = [int(i) for i in rng.integers(0, len(pool), int(rng.integers(1, 2 * B + 2)))]
-            print("next: %s %s" % (kind, ids), flush=True)
-            if kind == "host":
-                check("host batch", eng.detect_describe_batch(np.stack([pool[i] for i in ids])), ids)
-            elif kind == "device":
-                F = len(ids)
-                if F not in streams:
-                    streams[F] = smstream.FrameStream(eng, F)
-                fs = streams[F]
-                reps = int(rng.integers(1, 5))
-                d = smstream.DeviceFrames(np.stack([pool[i] for i in ids]))
-                for _ in range(reps):
-                    fs.run(d)
-                    if rng.random() < 0.5:
-                        fs.synchronize()
-                r = fs.results_host()
-                fs.synchronize()
-                d.close()
-                check("device batch x%d" % reps, (r["keypoints"], r["counts"][0], r["descriptors"], r["counts"][1]), ids)
-            elif kind == "single":
-                i = ids[0]
-                kps, counts = eng.detect(pool[i])
-                ds, dc = eng.describe(kps, counts)
-                check("detect+describe", (kps, counts[None], ds, dc[None]), [i])
-            elif kind == "approx":
-                i, j = ids[0], ids[-1]
-                m = eng.approximate_match(ref[i][2], ref[j][2])
-                want = pyoracle.approximate_match(ref[i][2]["features"].astype(np.int32), ref[j][2]["features"].astype(np.int32))
-                ok = np.array_equal(m["source"], want["source"]) and np.array_equal(m["target"], want["target"]) and \
-                    np.array_equal(m["distance"], want["distance"])
-                print("%s approximateMatch %d vs %d: %d matches" % ("ok  " if ok else "FAIL", i, j, len(m)), flush=True)
-                fails += 0 if ok else 1
-            elif kind == "geometry":
-                i, j = ids[0], ids[-1]
-                def xy(rec):            # absolute coordinates of each descriptor's keypoint (octave groups are concatenated)
-                    k, kc, d, dc = rec
-                    out, kp0, d0 = np.zeros((len(d), 2), np.float32), 0, 0
-                    for o in range(len(kc)):
-                        kk = k[kp0:kp0 + kc[o]]; dd = d[d0:d0 + dc[o]]
-                        out[d0:d0 + dc[o], 0] = kk["abs_x"][dd["keypoint"]]; out[d0:d0 + dc[o], 1] = kk["abs_y"][dd["keypoint"]]
-                        kp0 += kc[o]; d0 += dc[o]
-                    return out
-                axy, bxy = xy(ref[i]), xy(ref[j])
-                score, n = eng.match_geometry(ref[i][2], axy, ref[j][2], bxy)
-                mm = eng.match(ref[i][2], ref[j][2])
-                want = pyoracle.compare_geometry(mm[:80], axy, bxy) if len(mm) >= 7 else 0.0
-                ok = n == len(mm) and (score == want or (np.isnan(score) and np.isnan(want)) or abs(score - want) <= 1e-6 * abs(want))
-                print("%s matchGeometry %d vs %d: %d matches, score %.6f" % ("ok  " if ok else "FAIL", i, j, n, score), flush=True)
-                fails += 0 if ok else 1
-            else:
-                i, j = ids[0], ids[-1]
-                m = eng.match(ref[i][2], ref[j][2])
-                want = pyoracle.match(ref[i][2]["features"].astype(np.int32), ref[j][2]["features"].astype(np.int32))
-                ok = np.array_equal(m["source"], want["source"]) and np.array_equal(m["target"], want["target"])
-                if not ok:
-                    # The product forms exact integer distances, the oracle a sequential f32 sum; they can only disagree where a
-                    # threshold test is decided in the last ulp (best ~ second * 0.6) or two targets are exactly equidistant.  Verify with exact arithmetic.
-                    a = ref[i][2]["features"].astype(np.int64); b = ref[j][2]["features"].astype(np.int64)
-                    got_s, want_s = dict(zip(m["source"], m["target"])), dict(zip(want["source"], want["target"]))
-                    knife = True
-                    for src_i in set(got_s) ^ set(want_s) | {k for k in set(got_s) & set(want_s) if got_s[k] != want_s[k]}:
-                        d = np.sqrt(((b - a[src_i]) ** 2).sum(axis=1).astype(np.float64)) / 255.0
-                        bi = int(np.argmin(d)); sec = d[:bi].min() if bi else np.inf
-                        margin = abs(d[bi] - sec * 0.6) / max(d[bi], 1e-12)
-                        tie = int((np.abs(d - d[bi]) <= 1e-6 * max(d[bi], 1e-12)).sum()) > 1     # equal exact distances to different targets:
-                        knife = knife and (margin < 1e-5 or abs(d[bi] - 1.176) < 1e-5 or tie)    # the f32 sums order them by rounding noise
-                    ok = knife
-                    if ok:
-                        print("knife-edge threshold decision(s) differ from the f32 oracle", flush=True)
-                print("%s match %d vs %d: %d matches" % ("ok  " if ok else "FAIL", i, j, len(m)), flush=True)
-                fails += 0 if ok else 1
-        for fs in streams.values():
-            fs.close()
-        eng.close()
+    fails = sweep.api_sweep(sm, n_ops, seed, log=lambda s: print(s, flush=True))
     print("%d failures, %.0f s" % (fails, time.time() - t0), flush=True)
     return 1 if fails else 0
 

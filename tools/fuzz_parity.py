@@ -1,6 +1,7 @@
-"""Randomised parity sweep: random sizes / octave counts / scales per octave / image contents / pixel formats, every stage
-of the HIP path against the oracle (tests/parity.py::check_full_path).  Not part of the test suite (minutes of oracle
-time); run on the GPU box:  python tools/fuzz_parity.py [n_cases] [seed]"""
+"""Randomised parity sweep of any length and seed (tests/sweep.py: random sizes / octave counts / scales per octave / image contents /
+pixel formats / launch forms, every stage of the HIP path against the oracle).  A fixed-seed slice of it runs inside `pytest -m gpu`
+(tests/test_gpu_parity.py::test_seeded_parity_sweep); this tool is for longer runs on the GPU box:
+    python tools/fuzz_parity.py [n_cases] [seed] [nspo=3..7]"""
 import os
 import sys
 import time
@@ -10,87 +11,38 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 import siftmetal_amd as sm
-from tests import parity
-from tests.synth import blob_frame
-
-
-def make_image(rng, w, h):
-    kind = rng.choice(["blobs", "noise", "smooth", "checker", "constant", "steps", "blobs_f32", "blobs_bgra"])
-    if kind in ("blobs", "blobs_f32", "blobs_bgra"):
-        img = blob_frame(w, h, int(rng.integers(0, 1000)), n_blobs=int(rng.integers(3, 200)), gray=(kind != "blobs_bgra"))
-        if kind == "blobs_f32":
-            img = (img.astype(np.float32) / np.float32(255)).astype(np.float32)
-    elif kind == "noise":
-        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
-    elif kind == "smooth":
-        yy, xx = np.mgrid[0:h, 0:w]
-        img = (127 + 100 * np.sin(xx / rng.uniform(3, 40)) * np.cos(yy / rng.uniform(3, 40))).astype(np.uint8)
-    elif kind == "checker":
-        q = int(rng.integers(2, 24))
-        yy, xx = np.mgrid[0:h, 0:w]
-        img = ((((xx // q) + (yy // q)) & 1) * int(rng.integers(40, 255))).astype(np.uint8)
-    elif kind == "constant":
-        img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
-    else:
-        img = np.zeros((h, w), np.uint8)
-        img[:, w // 2:] = 200
-        img[h // 3:, :] //= 2
-    return kind, np.ascontiguousarray(img)
+from tests import sweep
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    kw = {"nspo_choices": (3, 3, 4, 5, 6, 7)} if (len(sys.argv) > 3 and sys.argv[3].startswith("nspo")) else {}
     rng = np.random.default_rng(seed)
     fails = ties = 0
+    worst_l2 = worst_theta = 0.0
     t0 = time.time()
     for case in range(n):
-        nspo = int(rng.choice([3, 3, 3, 4, 5]))
-        w = int(rng.integers(24, 700))
-        h = int(rng.integers(24, 500))
-        if rng.random() < 0.15:
-            w, h = int(rng.integers(700, 2100)), int(rng.integers(24, 160))         # wide strips
-        elif rng.random() < 0.15:
-            w, h = int(rng.integers(24, 160)), int(rng.integers(700, 2100))         # tall strips
-        elif rng.random() < 0.12:
-            w, h = int(rng.integers(1100, 2000)), int(rng.integers(700, 1100))      # a single large frame: tile blur with activity flags, flagged-row scan
-        max_oct = 1
-        while max_oct < 7 and min(2 * w, 2 * h) >> max_oct >= 12:
-            max_oct += 1
-        no = int(rng.integers(1, max_oct + 1))
-        kind, img = make_image(rng, w, h)
-        # blur / extrema code path: default (tile blur or, where it applies, the multi-layer chain kernel; full scan), the chain kernel
-        # off, marching blur + flagged-row extrema scan, marching blur only
-        mode = [{}, {}, {"blur_chain_max_tiles": -1}, {"blur_march_min_blocks": 1}, {"blur_march_min_blocks": 1, "count_raw_extrema": 1}][int(rng.integers(0, 5))]
-        tag = "case %d: %dx%d octaves %d nspo %d %s %s" % (case, w, h, no, nspo, kind, mode or "default")
+        c = sweep.parity_case(rng, **kw)
+        tag = "case %d: %s" % (case, sweep.describe_case(c))
         try:
-            try:
-                r = parity.check_full_path(sm, img, no, nspo, strict_theta=False, **mode)
-            except sm.SiftmiError as e:
-                if "capacity" not in str(e):
-                    raise
-                # dense synthetic patterns (checkerboards: 4 orientations per corner) overflow the default lists, which is a
-                # reported, recoverable condition: retry with explicit capacities
-                r = parity.check_full_path(sm, img, no, nspo, strict_theta=False, max_extrema=1 << 18, max_keypoints=1 << 17, max_descriptors=1 << 19, **mode)
-                tag += " (raised capacities)"
-            print("ok   %s -> %d keypoints" % (tag, r["keypoints"]), flush=True)
-        except AssertionError as e:
-            # Exactly symmetric patterns put many diagonal gradients (|dx| == |dy|) exactly on orientation-histogram bin
-            # boundaries and give every corner four equal peaks: 1-ulp differences between two atan2f implementations move
-            # whole samples between bins (~1 % of a peak), so peak counts and angles tie-break differently.  Reported
-            # separately: it is a tie, not a defect (see tests/parity.py::check_full_path).
-            msg = str(e)
-            if kind == "checker" and "max_dtheta" in msg:
-                ties += 1
-                print("tie  %s: %s" % (tag, msg), flush=True)
-            else:
-                fails += 1
-                print("FAIL %s" % tag, flush=True)
-                traceback.print_exc(limit=3)
+            r = sweep.run_parity_case(sm, c)
+            ties += 1 if (r["symmetric_pattern"] and r["max_dtheta"] > 2e-3) else 0
+            worst_l2 = max(worst_l2, r["max_l2_float"])
+            if not r["symmetric_pattern"]:
+                worst_theta = max(worst_theta, r["max_dtheta"])
+            print("ok   %s%s -> %d keypoints, %d of %d angles over 2e-3 rad (max %.2e)%s, descriptor L2 %.2e, %d bins differ" %
+                  (tag, " (raised capacities)" if r["raised_capacities"] else "", r["keypoints"], r["angles_over_tol"], r["angles_compared"], r["max_dtheta"],
+                   " [symmetric pattern]" if r["symmetric_pattern"] else "", r["max_l2_float"], r["bins_differing"]), flush=True)
+        except AssertionError:
+            fails += 1
+            print("FAIL %s" % tag, flush=True)
+            traceback.print_exc(limit=3)
         except Exception as e:
             fails += 1
             print("ERR  %s: %r" % (tag, e), flush=True)
-    print("%d cases, %d failures, %d orientation ties on symmetric patterns, %.0f s" % (n, fails, ties, time.time() - t0), flush=True)
+    print("%d cases, %d failures, %d symmetric patterns with angles past 2e-3 rad, worst descriptor L2 %.2e, worst dtheta elsewhere %.2e, %.0f s" %
+          (n, fails, ties, worst_l2, worst_theta, time.time() - t0), flush=True)
     return 1 if fails else 0
 
 
