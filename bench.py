@@ -60,14 +60,17 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def make_frames(n, distinct):
-    """n synthetic frames, `distinct` of them different (default: all) -- generated on a few host threads (0.25 s per frame)."""
+def make_frames(n, distinct, indices=None):
+    """n synthetic frames, `distinct` of them different (default: all) -- generated on a few host threads (0.25 s per frame).
+    indices: positions in the (endless) synthetic stream, frame g = blob field g mod distinct; default 0 ... n-1."""
     from concurrent.futures import ThreadPoolExecutor
     from tests.synth import blob_frame
-    k = min(n, distinct)
+    idx = list(range(n)) if indices is None else list(indices)
+    k = max(min(n, distinct) if indices is None else distinct, 1)
+    need = sorted(set(g % k for g in idx))
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        base = list(ex.map(lambda i: blob_frame(W, H, i), range(k)))
-    return np.stack([base[i % k] for i in range(n)])
+        base = dict(zip(need, ex.map(lambda i: blob_frame(W, H, i), need)))
+    return np.stack([base[g % k] for g in idx])
 
 
 def match_extra(eng, local_rank):
@@ -315,9 +318,10 @@ def main():
     from siftmetal_amd import _capi, stream as smstream
 
     F = args.frames
-    frames_np = make_frames(F, args.distinct)
-    # every rank gets different frames (rotate) so the gathered descriptors are not copies
-    frames_np = np.roll(frames_np, rank, axis=0)
+    # the stream of world x F frames per step, sharded frame-per-GPU by the rule the library's hosts use (stream.shard_frames: frame g -> rank
+    # g mod world): this rank takes frames rank, rank + world, ... (one rank: frames 0 ... F-1)
+    my_frames = smstream.shard_frames(world * F, world, rank)
+    frames_np = make_frames(F, args.distinct, my_frames)
     hpin = sm.pinned_empty(frames_np.shape, np.uint8)            # the frames as a capture loop delivers them: page-locked host memory
     hpin[...] = frames_np
     d_frames = smstream.DeviceFrames(frames_np, local_rank)      # HBM through siftmi_device_alloc / siftmi_memcpy (the resident figure, roofline pass)
@@ -413,6 +417,34 @@ def main():
                     "records_gathered": [int(sum(len(x) for x in gh["keypoints"])), int(sum(len(x) for x in gh["descriptors"]))]}
 
     res = runner.results_host()
+    by_rank = None
+    if use_dist:
+        # What every rank did, gathered over the control plane (gloo), so that the first real multi-GPU record shows WHERE weak scaling goes if
+        # it goes: per-rank step time, device, NUMA node, frames, and the page-locked -> HBM copy rate with every rank copying AT THE SAME TIME
+        # (N x 57 GB/s is ~460 GB/s of host-memory reads on an 8-GPU node).  And the row check: row r of the gathered step is rank r's own
+        # packed result, byte for byte (crc32), or the line is not printed.
+        import zlib
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            _capi.check(_capi.load().siftmi_memcpy(d_frames.ptr, hpin.ctypes.data, hpin.nbytes, 0))
+        my_h2d = 3 * hpin.nbytes / (time.perf_counter() - t1) / 1e9
+        own_crc = zlib.crc32(res["descriptors"].tobytes(), zlib.crc32(res["keypoints"].tobytes(), 0))
+        mine = {"rank": rank, "device": local_rank, "host_numa_node": numa_node, "ms_per_step": round(rank_ms[rank] if world > 1 else rank_ms[0], 4),
+                "concurrent_h2d_GBps": round(my_h2d, 1), "frames": [int(g) for g in my_frames[:4]] + (["..."] if len(my_frames) > 4 else []),
+                "own_results_crc32": "%08x" % own_crc, "keypoints": int(res["n_keypoints"]), "descriptors": int(res["n_descriptors"])}
+        everyone = [mine]
+        if world > 1:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+        gh = runner.exchange.result_host(0)
+        rows = ["%08x" % zlib.crc32(gh["descriptors"][r].tobytes(), zlib.crc32(gh["keypoints"][r].tobytes(), 0)) for r in range(world)]
+        if rows != [e["own_results_crc32"] for e in everyone]:
+            raise SystemExit("bench: a row of the gathered step is not that rank's own result (rows %s, own %s)" % (rows, [e["own_results_crc32"] for e in everyone]))
+        by_rank = {k: [e[k] for e in everyone] for k in mine}
+        by_rank["gathered_row_equals_own_result"] = True
+        by_rank["sharding"] = "stream.shard_frames: frame g of the %d-frame step -> rank g mod %d" % (world * F, world)
     if (res["n_keypoints"], res["n_descriptors"]) != (first["n_keypoints"], first["n_descriptors"]) or \
             not np.array_equal(res["counts"], first["counts"]):
         raise SystemExit("bench: results of the last timed step differ from the first step (%d/%d vs %d/%d keypoints/descriptors): "
@@ -442,6 +474,7 @@ def main():
                       "ranks_share_one_gpu": bool(args.share_gpu),
                       "all_gather_transport": transport,
                       "ms_per_step_by_rank": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
+                      "by_rank": by_rank,
                       "all_gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4),
                       "all_gather_bytes_received_per_rank_per_step": gather_bytes,
                       "all_gather_steps_regathered": regathered, "all_gather_steps_overflowed": overflowed,

@@ -1588,3 +1588,65 @@ def test_bench_line_with_the_exchange_on_one_rank():
     assert c["all_gather_ms_per_step"] > 0 and c["all_gather_bytes_received_per_rank_per_step"] > 10 ** 6
     assert c["all_gather_steps_overflowed"] == 0 and c["all_gather_steps_regathered"] == 0
     assert c["ms_per_step_by_rank"]["min"] == c["ms_per_step_by_rank"]["max"] > 0
+    # the per-rank report of the N > 1 line, and the row check (row r of the gathered step = rank r's own packed result)
+    b = c["by_rank"]
+    assert b["rank"] == [0] and b["device"] == [0] and b["frames"][0][:4] == [0, 1, 2, 3] and b["gathered_row_equals_own_result"]
+    assert b["concurrent_h2d_GBps"][0] > 5 and b["ms_per_step"][0] == c["ms_per_step_by_rank"]["max"]
+    # N = 1 with the exchange = the plain N = 1 line (what BENCH_rNN.json records): the all-gather runs on a side stream under the next
+    # step's kernels and must not cost the step anything
+    d1 = json.loads(lines[0])
+    p0 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras", "--no-roofline"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p0.returncode == 0, p0.stderr.decode()[-2000:]
+    d0 = json.loads([ln for ln in p0.stdout.decode().splitlines() if ln.strip()][-1])
+    assert d0["config"]["by_rank"] is None and d0["config"]["rccl_ranks"] == 0
+    assert d1["value"] >= 0.9 * d0["value"], (d1["value"], d0["value"])
+    assert (d1["config"]["keypoints_per_step_rank0"], d1["config"]["descriptors_per_step_rank0"]) == \
+        (d0["config"]["keypoints_per_step_rank0"], d0["config"]["descriptors_per_step_rank0"])
+
+
+def test_bench_eight_ranks_share_the_gpu():
+    """The launch the driver's 8-GPU scaling run uses -- `bench.py --gpus 8`: self-launch through torch.distributed.run, rank -> device,
+    NUMA pinning, unique-id broadcast, siftmi_exchange_* with EIGHT ranks, one JSON line -- on the one GPU this box has: --share-gpu puts
+    every rank on device 0 and SIFTMI_RCCL_LIB points the exchange at tests/c/libfake_rccl.so (real RCCL refuses two ranks per device).
+    Small steps (4 frames per rank).  Checked: ncclCommCount == 8, the frame-per-GPU rule (rank r takes frames r, r + 8, ...), every rank's
+    view of the gathered step equal (crc32), row r of it = rank r's own packed result = what a fresh context computes for THOSE frames."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import zlib
+    import siftmetal_amd as sm
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = os.path.join(root, "tests", "c", "libfake_rccl.so")
+    assert os.path.exists(fake), "tests/c/libfake_rccl.so is built by __graft_entry__.build()"
+    env = dict(os.environ, SIFTMI_RCCL_LIB=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SIFTMI_FORCE_GATHER", None)
+    N, F, DISTINCT = 8, 4, 32
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(N), "--share-gpu", "--frames", str(F), "--batch", str(F),
+                        "--distinct", str(DISTINCT), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras", "--no-roofline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == N and d["scaling"] == "weak" and c["rccl_ranks"] == N and c["ranks_share_one_gpu"] and "fake_rccl" in c["all_gather_transport"]
+    assert abs(d["value"] - N * F * 1920 * 1080 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3           # whole-job pixels / max-over-ranks time
+    ck = c["all_gather_checksum"]
+    assert ck["equal_on_all_ranks"] and ck["ranks_compared"] == N
+    b = c["by_rank"]
+    assert b["rank"] == list(range(N)) and b["device"] == [0] * N and b["gathered_row_equals_own_result"]
+    assert all(b["frames"][r] == [r, r + N, r + 2 * N, r + 3 * N] for r in range(N)), b["frames"]
+    assert len(set(b["host_numa_node"])) == 1                                                            # one GPU: one node (or None where the topology is unreadable)
+    assert max(b["ms_per_step"]) == c["ms_per_step_by_rank"]["max"] and min(b["ms_per_step"]) > 0 and all(g > 1 for g in b["concurrent_h2d_GBps"])
+    assert ck["records_gathered"] == [sum(b["keypoints"]), sum(b["descriptors"])]
+    assert c["all_gather_steps_overflowed"] == 0
+    # rank r's own result (= row r of every rank's gathered step) is what a fresh context computes for frames r, r + 8, r + 16, r + 24
+    sys.path.insert(0, root)
+    import bench
+    eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=F)
+    for r in (0, 5, 7):
+        k, kc, ds, dc = eng.detect_describe_batch(bench.make_frames(F, DISTINCT, [r + N * i for i in range(F)]))
+        assert "%08x" % zlib.crc32(ds.tobytes(), zlib.crc32(k.tobytes(), 0)) == b["own_results_crc32"][r], r
+    eng.close()
