@@ -356,6 +356,9 @@ typedef struct siftmi_gathered {
 int  siftmi_exchange_unique_id(void *id /* SIFTMI_UNIQUE_ID_BYTES */);
 /* collective over the `world` ranks: ncclCommInitRank on the stream's device */
 int  siftmi_exchange_create(siftmi_stream *s, const void *unique_id, int rank, int world, siftmi_exchange **out);
+/* bounded like every wait of the exchange: a healthy exchange drains its pending gathers (within the timeout) and frees everything; a
+   FAILED one (a wait expired, the communicator reported an error) is aborted, and if its stream still has not drained by the deadline
+   its buffers, stream and communicator are leaked rather than waited for (siftmi_last_error() says so) */
 void siftmi_exchange_destroy(siftmi_exchange *x);
 /* what the communicator itself reports (ncclCommCount / ncclCommUserRank); siftmi_exchange_create has checked both against its
    arguments */
@@ -412,7 +415,9 @@ int siftmi_match_descriptors(siftmi_ctx *ctx, const siftmi_descriptor *source, i
 /* The same match with everything staying in HBM: descriptors in device memory, the records of the matched sources packed in source
    order into d_matches (device, capacity n_source records) and their number into *d_count (device); asynchronous on `stream`
    (hipStream_t, NULL = the context's stream), no host synchronisation -- a consumer on the device (RANSAC, a tracker) reads them from
-   there, a host reads *d_count when it needs it.  Scratch is the context's: calls on one context are ordered on the device. */
+   there, a host reads *d_count when it needs it.  Scratch is the context's: calls on one context are ordered on the device.
+   The FIRST call of a context, and any call whose sizes outgrow the scratch of the earlier ones, reallocates it (hipFree / hipMalloc:
+   a device-wide synchronisation, once); size the first call for the largest sets to come and later calls enqueue without one. */
 int siftmi_match_descriptors_device(siftmi_ctx *ctx, const siftmi_descriptor *d_source, int64_t n_source,
                                     const siftmi_descriptor *d_target, int64_t n_target,
                                     float absolute_threshold, float relative_threshold,

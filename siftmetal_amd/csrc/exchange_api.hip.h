@@ -16,6 +16,8 @@
 // (SIFTMI_EXCHANGE_TIMEOUT_S, default 120 s per wait; siftmi_exchange_set_timeout), then aborts the communicator (ncclCommAbort makes
 // the collective kernels that are stuck on the device exit, so the streams ordered behind them drain) and returns SIFTMI_E_HIP naming
 // the rank and the step.  An aborted exchange fails every later call the same way; nothing is restarted.
+// siftmi_exchange_destroy is bounded too: if an aborted exchange's stream has not drained by the deadline, its buffers, stream and
+// communicator are leaked instead of freed (hipFree / ncclCommDestroy would wait for the stuck stream).
 #pragma once
 #include <rccl/rccl.h>
 #include <chrono>
@@ -136,6 +138,7 @@ struct siftmi_exchange {
     int comm_ranks = 0, comm_rank = -1;           // what the communicator itself reports (ncclCommCount / ncclCommUserRank)
     double timeout_s = 120.0;                     // deadline of every host wait (SIFTMI_EXCHANGE_TIMEOUT_S)
     bool failed = false;                          // a wait expired or the communicator reported an error: aborted, every call fails
+    bool abort_on_destroy = false;                // creation was refused after ncclCommInitRank: the communicator is aborted, not destroyed
     std::string fail_msg;
     hipEvent_t ev_wait = nullptr;                 // siftmi_exchange_wait / finish / destroy: "everything enqueued so far"
     hipStream_t gstream = nullptr;
@@ -213,14 +216,29 @@ extern "C" void siftmi_exchange_destroy(siftmi_exchange *x) {
     (void)hipSetDevice(x->s->device);
     // a gather that can no longer complete (a peer is gone) must not hang the teardown: bounded, then aborted
     if (x->gstream && x->ev_wait && !x->failed) (void)exchange_drain(x, "the pending gathers at destroy");
+    bool drained = true;
     if (x->gstream && x->failed) {                                                // aborted collectives exit; bounded all the same
         const auto t0 = std::chrono::steady_clock::now();
         while (hipStreamQuery(x->gstream) == hipErrorNotReady &&
                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < x->timeout_s)
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        drained = hipStreamQuery(x->gstream) != hipErrorNotReady;
         (void)hipGetLastError();
     }
-    if (x->comm) (void)rccl().CommDestroy(x->comm);
+    // the result sets must not wait for events of this exchange any more
+    for (auto &rs : x->s->sets) rs.gather_rec = false;
+    if (!drained) {
+        // The abort did not make the stuck collective leave the stream within the deadline (or a peer died between the drain and here).
+        // hipFree / hipStreamDestroy / ncclCommDestroy would each wait for that stream -- for ever.  The teardown of a failed exchange
+        // stays bounded instead: buffers, stream and communicator are LEAKED (the process is about to end: bench.py exits
+        // non-zero on a failed exchange) and the caller is told.
+        set_error(SIFTMI_E_HIP, "exchange (rank %d of %d): the gather stream did not drain within %.0f s after the abort; its buffers and communicator are leaked",
+                  x->rank, x->world, x->timeout_s);
+        delete x;
+        return;
+    }
+    // a communicator that failed (or whose creation was refused below) is aborted, not destroyed: ncclCommDestroy waits for the peers
+    if (x->comm) (void)((x->failed || x->abort_on_destroy) ? rccl().CommAbort(x->comm) : rccl().CommDestroy(x->comm));
     if (x->ev_wait) (void)hipEventDestroy(x->ev_wait);
     for (auto &g : x->g) {
         void *ptrs[] = {g.kp, g.desc, g.counts, g.totals};
@@ -230,8 +248,6 @@ extern "C" void siftmi_exchange_destroy(siftmi_exchange *x) {
         hipEvent_t evs[] = {g.ev_done, g.ev_totals, g.t0, g.t1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
-    // the result sets must not wait for events of this exchange any more
-    for (auto &rs : x->s->sets) rs.gather_rec = false;
     if (x->gstream) (void)hipStreamDestroy(x->gstream);
     delete x;
 }
@@ -278,6 +294,7 @@ extern "C" int siftmi_exchange_create(siftmi_stream *s, const void *unique_id, i
     ncclResult_t r1 = rccl().CommCount(x->comm, &x->comm_ranks), r2 = rccl().CommUserRank(x->comm, &x->comm_rank);
     if (r1 != ncclSuccess || r2 != ncclSuccess || x->comm_ranks != world || x->comm_rank != rank) {
         rc = set_error(SIFTMI_E_HIP, "communicator reports rank %d of %d, expected rank %d of %d [%s]", x->comm_rank, x->comm_ranks, rank, world, rccl().origin.c_str());
+        x->abort_on_destroy = true;                                                   // (the peers of a mis-launched job may never call destroy)
         siftmi_exchange_destroy(x);
         return rc;
     }

@@ -397,23 +397,53 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const int4 *__restr
 // buffer, and their number -- the reference's output array (SIFTDescriptor.swift:304-317 appends in source order) without a host round
 // trip.  A block's offset is the sum of the per-block match counts match_finalize_kernel left (n / 256 values), then a ballot scan
 // inside the block; the last block writes the total.
+// prefixed = 0: every block sums the counts of the blocks before it itself -- b reads for block b, which is nothing at call sizes (a
+// 100 k-source call has 390 blocks) but quadratic; from 1024 blocks on the host enqueues match_block_prefix_kernel first (one workgroup,
+// exclusive scan in place) and passes prefixed = 1 (the API accepts up to 2^30 sources).
+__global__ __launch_bounds__(1024) void match_block_prefix_kernel(int32_t *__restrict__ block_count, int n_blocks) {
+    __shared__ int wsum[16], s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_blocks; i0 += 1024) {
+        const int i = i0 + tid;
+        const int v = i < n_blocks ? block_count[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int before = s_carry + incl - v;
+        for (int k = 0; k < wv; k++) before += wsum[k];
+        if (i < n_blocks) block_count[i] = before;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + v;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void match_compact_kernel(const MatchRec *__restrict__ all, int n_src, const int32_t *__restrict__ block_count,
-                                                           MatchRec *__restrict__ out, int32_t *__restrict__ count) {
+                                                           int prefixed, MatchRec *__restrict__ out, int32_t *__restrict__ count) {
     __shared__ int wsum[4], s_before;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int before = 0;
-    for (int i = tid; i < (int)blockIdx.x; i += 256) before += block_count[i];
+    if (prefixed) {
+        if (tid == 0) s_before = block_count[blockIdx.x];
+    } else {
+        int before = 0;
+        for (int i = tid; i < (int)blockIdx.x; i += 256) before += block_count[i];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o, 64);
-    if (lane == 0) wsum[wv] = before;
-    __syncthreads();
-    if (tid == 0) s_before = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o, 64);
+        if (lane == 0) wsum[wv] = before;
+        __syncthreads();
+        if (tid == 0) s_before = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
     __syncthreads();
     const int s = blockIdx.x * 256 + tid;
     MatchRec rec; rec.source = s; rec.target = -1; rec.distance = 0.0f;
     if (s < n_src) rec = all[s];
     const bool hit = rec.target >= 0;
     const unsigned long long b = __ballot(hit);
+    __syncthreads();
     if (lane == 0) wsum[wv] = __popcll(b);
     __syncthreads();
     int pos = s_before + __popcll(b & ((1ull << lane) - 1ull));

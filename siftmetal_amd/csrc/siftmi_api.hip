@@ -410,7 +410,11 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     }
     const size_t B = (size_t)c->B, G = B * c->n_oct;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 16)); };
-    alloc((void **)&c->d_gauss, B * off * sizeof(float));
+    // + 64 B: the quad walks of the orientation / descriptor kernels read up to 8 B past a row's last candidate through the SGPR row
+    // offset, which the buffer resource's range check does not see (it bounds the VGPR offset).  A described layer is never the stack's
+    // last (scale <= nspo of nspo + 3 layers), so such a read lands in the next layer -- or, for the last frame's last octave at most,
+    // in this tail; the values are never used.
+    alloc((void **)&c->d_gauss, B * off * sizeof(float) + 64);
     c->input_bytes = (size_t)W * H * 4;
     alloc((void **)&c->d_input, 2 * B * c->input_bytes);
     alloc((void **)&c->d_ext, B * ext_off * sizeof(ExtremumRec));
@@ -1288,7 +1292,11 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     // sub-batch count doubles the signatures of a call shape (9 sub-batches x 2 slots cycling through a 16-entry candidate
     // list were never captured).  The previous host call has synchronised, both slots are free (and ev_consumed still orders them).
     c->input_slot = 0;
-    c->graph_min_cap = std::max(c->graph_min_cap, (size_t)n_sub + 8);
+    // ... and a call of n sub-batches needs n signatures alive at once, so the cache grows with the largest call seen -- up to 256 graphs
+    // (a hipGraphExec of this launch sequence holds ~40 kernel nodes with their kernargs); a call of more sub-batches than that cycles
+    // through the cache (least recently used out, sequences captured again: correct, only slower) instead of pinning thousands of graphs
+    // for the life of the context.
+    c->graph_min_cap = std::min<size_t>(std::max(c->graph_min_cap, (size_t)n_sub + 8), 256);
     HIP_TRY(c->h_sub.resize(4 * (size_t)n_sub));
     HIP_TRY(c->h_kp.resize(1)); HIP_TRY(c->h_desc.resize(1));          // (callers get non-null pointers for empty results too)
     while ((int)c->ev_sub.size() < n_sub) {
@@ -1688,9 +1696,14 @@ extern "C" int siftmi_match_descriptors_device(siftmi_ctx *c, const siftmi_descr
     }
     int32_t *block_count = nullptr;
     if ((rc = enqueue_match(c, st, (const DescriptorRec *)d_source, n_source, (const DescriptorRec *)d_target, n_target, absolute_threshold, relative_threshold,
-                            &block_count)))
+                            &block_count))) {
+        (void)order_end(c, st);                                               // whatever was enqueued before the failure stays ordered
         return rc;
-    hipLaunchKernelGGL(match_compact_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, c->d_match_out, (int)n_source, block_count,
+    }
+    const int n_blocks = (int)((n_source + 255) / 256);
+    const int prefixed = n_blocks >= 1024 ? 1 : 0;                            // (match_compact_kernel: the in-block sum is quadratic in the block count)
+    if (prefixed) hipLaunchKernelGGL(match_block_prefix_kernel, dim3(1), dim3(1024), 0, st, block_count, n_blocks);
+    hipLaunchKernelGGL(match_compact_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, c->d_match_out, (int)n_source, block_count, prefixed,
                        (MatchRec *)d_matches, d_count);
     HIP_TRY(hipGetLastError());
     return order_end(c, st);

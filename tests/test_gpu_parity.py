@@ -744,7 +744,8 @@ def test_match_large_bounded_chunks_sampled_sources_vs_oracle(sm, n_src, n_tgt):
     assert len(want) > 0.9 * len(sample)
 
 
-@pytest.mark.parametrize("n_src,n_tgt", [(1, 1), (255, 40), (256, 257), (2500, 2300), (20000, 7000), (70001, 50003)])
+@pytest.mark.parametrize("n_src,n_tgt", [(1, 1), (255, 40), (256, 257), (2500, 2300), (20000, 7000), (70001, 50003),
+                                         (262144 + 300, 900)])     # >= 1024 source blocks: the compaction's offsets come from the prefix launch
 def test_match_device_output_equals_host_call(sm, n_src, n_tgt):
     """siftmi_match_descriptors_device: descriptors in HBM, the matched records packed in source order into device memory and their
     number beside them, no host synchronisation inside the call -- byte-equal to what siftmi_match_descriptors returns on the host
