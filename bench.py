@@ -510,6 +510,16 @@ def main():
         rrun.close()
         log("resident frames: %.3f ms/step (%.0f Mpixels/s); synchronous H2D %.1f GB/s -> upload floor %.3f ms/step" %
             (out["resident_ms_per_step"], out["resident_Mpixels_per_s"], h2d_gbs, out["h2d_floor_ms"]))
+        if not args.no_extras and not use_dist:
+            # `value` times EXACTLY K steps between device synchronisations, so it pays one pipeline fill (nothing runs under the first
+            # upload) and one drain (the last step's kernels run after the last upload) per K steps: ~one step's kernels / K.  The same
+            # host-fed loop over 10 K steps shows the steady rate of the stream, which is what a capture loop sees.
+            ks = 10 * args.steps
+            dts = timed_steps(step, barrier, ks, 0)
+            out["config"]["steady_state"] = {"steps": ks, "ms_per_step": round(dts / ks * 1e3, 4), "Mpixels_per_s": round(F * W * H * ks / dts / 1e6, 1),
+                                             "what": "the host-fed loop of `value` over %d steps in one timed region: the fill / drain of a region amortised "
+                                                     "over 10x as many steps" % ks}
+            log("host-fed, %d steps in one region: %.3f ms/step (%.0f Mpixels/s)" % (ks, dts / ks * 1e3, out["config"]["steady_state"]["Mpixels_per_s"]))
         # the same K resident steps one at a time on one context: what the pipelining buys
         dt1 = timed_steps(lambda: plain.run(d_frames), dev_sync, args.steps, 3)
         out["resident_ms_per_step_one_in_flight"] = round(dt1 / args.steps * 1e3, 4)

@@ -115,7 +115,7 @@ def test_swift_stub_files_match_integration_md():
     blocks = re.findall(r"```(\w*)\n(.*?)```", txt, re.S)
     modmap = [b for lang, b in blocks if b.startswith("module CSiftmi")]
     swift = [b for lang, b in blocks if lang == "swift"]
-    assert len(modmap) == 1 and len(swift) == 3
+    assert len(modmap) == 1 and len(swift) == 4
     sw = os.path.join(ROOT, "swift", "Sources")
     assert open(os.path.join(sw, "CSiftmi", "module.modulemap")).read() == modmap[0]
     assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X.swift")).read() == swift[0]
@@ -127,12 +127,18 @@ def test_swift_stub_files_match_integration_md():
         assert re.search(r"public static func %s\(source: \[SIFTDescriptor\], target: \[SIFTDescriptor\],\s*absoluteThreshold: Float = %s, relativeThreshold: Float = 0.6\)" % (name, re.escape(dflt)), ext), name
     assert "-> [SIFTCorrespondence]" in ext and "-> Float" in ext
     assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Stream.swift")).read() == swift[2]
+    # the reference's other public compute types: same names, the reference's Configuration defaults
+    assert open(os.path.join(sw, "SIFTMetal", "SIFT", "SIFT+MI355X+Kernels.swift")).read() == swift[3]
+    assert "public final class DifferenceOfGaussians {" in swift[3] and "public final class SIFTDescriptorKernel {" in swift[3]
+    for field, dflt in (("sigmaMinimum", "0.8"), ("deltaMinimum", "0.5"), ("sigmaInput", "0.5"), ("numberOfOctaves", "7"), ("numberOfScalesPerOctave", "3")):
+        assert re.search(r"var %s: \w+ = %s\b" % (field, re.escape(dflt)), swift[3]), field
+    assert "public init(inputDimensions: IntegralSize)" in swift[3] and "public func encode(" in swift[3]
     # every siftmi_* symbol the Swift uses is declared in the header
     hdr = open(os.path.join(ROOT, "include", "siftmi.h")).read()
-    used = set(re.findall(r"\b(siftmi_[a-z_0-9]+)\s*\(", swift[0] + swift[1] + swift[2]))
+    used = set(re.findall(r"\b(siftmi_[a-z_0-9]+)\s*\(", swift[0] + swift[1] + swift[2] + swift[3]))
     structs = {"siftmi_config", "siftmi_keypoint", "siftmi_descriptor", "siftmi_stream_config", "siftmi_step_host", "siftmi_gathered"}
     assert used and all(re.search(r"\b%s\s*\(" % u, hdr) for u in used - structs), used
-    assert "siftmi_stream_submit_host" in used and "siftmi_exchange_gather" in used
+    assert "siftmi_stream_submit_host" in used and "siftmi_exchange_gather" in used and "siftmi_copy_dog" in used and "siftmi_copy_gaussian" in used
     man = open(os.path.join(ROOT, "swift", "Package.swift")).read()
     assert '.systemLibrary(name: "CSiftmi"' in man and '.linkedLibrary("siftmi")' in man
 
