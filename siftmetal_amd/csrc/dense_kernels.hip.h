@@ -539,13 +539,11 @@ struct VTapsSym {                   // w[i] for i <= R; w[2R - i] beyond (bit-id
 // 0.454 -> 0.445; nothing at R = 10 and 13 (0.511 / 0.607 either way, also with 168 registers per lane) -- those layers sit at
 // the FMA issue rate three waves per SIMD reach (tools/ubench/ubench_valu: 3.4 / 2.9 / 2.7 cycles per v_fma_f32 at 2 / 4 / 8
 // waves), not at LDS latency.  On for R <= 8.
-// VM (round 3 experiment, tools/ubench only; 0 in the library): the vertical pass on the matrix cores.  An f32 MFMA is a k-ordered
-// fmaf chain, so tile = T (banded tap matrix) x window gives every output its 2R + 1 taps in the reference's order between exact
-// zeros: bit-identical.  1 = v_mfma_f32_4x4x1 (16 blocks, four 4-row chains per wavefront), 2 = v_mfma_f32_16x16x1 (4 blocks).
-// Both slower than the vector form (profiles/blur_variants_r03_mfma_vertical.log): the f32 matrix rate IS the vector rate, and
-// the other wavefronts' horizontal passes do not speed up beside the MFMAs.
+// (The vertical pass on the matrix cores -- v_mfma_f32_4x4x1 / 16x16x1 against the banded tap matrix, bit-identical, slower: the f32 matrix
+// rate IS the vector rate -- was a template branch of this kernel in rounds 3-5; it now lives in tools/experiments/blur_mfma_vertical_r03.diff,
+// results in profiles/blur_variants_r03_mfma_vertical.log.)
 template <int R, int MINW = 4, int S_ = 32, bool DEC = false, bool ACT = false, int DBG = 0, int SEEDF = -1, bool H8 = (R <= 12),
-          bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */, int VM = 0>
+          bool HPIPE = (R <= 7) || (R == 8 && !(DEC && ACT)) /* that one instantiation would spill 4 registers */>
 __global__ __launch_bounds__(8 * S_, MINW) void blur_ring_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                              size_t src_frame_stride, size_t dst_frame_stride, TapWeights wt,
                                                              int n_frames, int ch_rows /* rows per chunk, a multiple of S */, Decimate dec, Activity act,
@@ -690,19 +688,6 @@ __global__ __launch_bounds__(8 * S_, MINW) void blur_ring_kernel(const float *__
         stage_rows(-2 * R, S);
     }
     const VTapsSym<R> tw(wt);
-    // VM: column k of the banded tap matrix, row i = lane % TM of a TM-row tile: tap k - i, zero outside the band
-    constexpr int TM = VM == 2 ? 16 : 4;
-    float va[VM ? TM + 2 * R : 1];
-    if (VM) {
-#pragma unroll
-        for (int k = 0; k < TM + 2 * R; k++) {
-            float wq = 0.0f;
-#pragma unroll
-            for (int i = 0; i < TM; i++) { const int t = k - i; if (t >= 0 && t < G::NT) wq = ((lane & (TM - 1)) == i) ? wt.w[t] : wq; }
-            va[k] = wq;
-        }
-    }
-
     unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
     auto stamp = [&](int k) {                                // DBG & 1: time since the previous stamp -> dsum[k]
         if (!(DBG & 1)) return;
@@ -834,87 +819,6 @@ __global__ __launch_bounds__(8 * S_, MINW) void blur_ring_kernel(const float *__
         lds_barrier();                                       // B2: blurred rows complete
         stamp(2);
 
-        if constexpr (VM == 2) {
-            // vertical pass on the matrix cores, 16 x 64 tile of wavefront wv = T(16 x K) B(K x 64), K = 16 + 2R window rows: one
-            // v_mfma_f32_16x16x1 (4 blocks of 16 columns, 32 cycles of the matrix pipe but 8 of the SIMD's issue) per window row.
-            // Lane (b = lane / 16, n = lane % 16) feeds column 4 n + b of block b and ends up with columns 4 n ... 4 n + 3 of rows
-            // 4 (lane / 16) + v: one b128 store per row.
-            static_assert(S == 32 && !ACT && !DEC, "VM: 2 x 2 tiles of 16 x 64 per step");
-            const int tr = (wv >> 1) * 16, tc = (wv & 1) * 64;
-            const int u0 = st * S + tr - 2 * R;              // even
-            const int n = lane & 15, g = lane >> 4;
-            const int col = RP + tc + 4 * n + g;
-            const float *colp = lds + col, *colx = lds + (col ^ (H8 ? 4 : 0));
-            float bv[16 + 2 * R];
-#pragma unroll
-            for (int r = 0; r < 16 + 2 * R; r++) {
-                const int slot = (u0 + r + NR) & (NR - 1);
-                bv[r] = *(const lds_cv_f32 *)(((r & 1) ? colx : colp) + slot * LW);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-#pragma unroll
-            for (int r = 0; r < ((DBG & 16) ? 0 : 16 + 2 * R); r++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(va[r], bv[r], acc, 0, 0, 0);
-            stamp(3);
-            const int gx = x0 + tc + 4 * n;
-#pragma unroll
-            for (int v = 0; v < ((DBG & 2) ? 0 : 4); v++) {
-                const int gy = y0 + tr + 4 * g + v;
-                if (!FULL && gy >= h) continue;
-                float *o = out + (size_t)gy * w + gx;
-                const f32x4 q = {acc[v], acc[4 + v], acc[8 + v], acc[12 + v]};
-                if (FULL || (gx + 3 < w && (w & 3) == 0)) {
-                    *reinterpret_cast<f32x4 *>(o) = q;
-                } else {
-                    if (gx + 0 < w) o[0] = q.x;
-                    if (gx + 1 < w) o[1] = q.y;
-                    if (gx + 2 < w) o[2] = q.z;
-                    if (gx + 3 < w) o[3] = q.w;
-                }
-            }
-        } else
-        if constexpr (VM == 1) {
-            // vertical pass on the matrix cores: a 4-row x 64-column tile is T(4 x K) B(K x 64) with K = 4 + 2R window rows and T the
-            // banded tap matrix, one v_mfma_f32_4x4x1 (16 blocks of 4 columns) per window row -- per output a k-ordered fmaf chain
-            // over its 2R + 1 taps with exact zeros before and after: bit-identical to the vector form.  Wavefront wv owns rows
-            // (wv >> 1) 16 ..., columns (wv & 1) 64 ... as four such tiles (four independent accumulator chains, a window row
-            // feeds up to four of them); lane l feeds column l and ends up with column l of the 16 rows.
-            static_assert(S == 32 && !ACT && !DEC, "VM: 2 x 2 tiles of 16 x 64 per step");
-            const int tr = (wv >> 1) * 16, tc = (wv & 1) * 64;
-            const int u0 = st * S + tr - 2 * R;              // even
-            const int col = RP + tc + lane;
-            const float *colp = lds + col, *colx = lds + (col ^ (H8 ? 4 : 0));
-            f32x4 acc[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            float bv[16 + 2 * R];                            // the whole window first: one LDS latency, not one per row
-#pragma unroll
-            for (int r = 0; r < 16 + 2 * R; r++) {
-                const int slot = (u0 + r + NR) & (NR - 1);
-                bv[r] = *(const lds_cv_f32 *)(((r & 1) ? colx : colp) + slot * LW);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < ((DBG & 16) ? 0 : 16 + 2 * R); r++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int k = r - 4 * q;
-                    if (k >= 0 && k < 4 + 2 * R) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(va[k], bv[r], acc[q], 0, 0, 0);
-                }
-            }
-            stamp(3);
-            const int gx = x0 + tc + lane;
-            if (FULL || gx < w) {
-#pragma unroll
-                for (int j = 0; j < ((DBG & 2) ? 0 : 16); j++) {
-                    const int gy = y0 + tr + j;              // wave-uniform
-                    if (!FULL && gy >= h) continue;
-                    out[(size_t)gy * w + gx] = acc[j >> 2][j & 3];
-                }
-            }
-        } else
         // vertical pass: wavefront wv owns output rows wv RB ... wv RB + RB - 1 of the step, a lane 2 columns
         {
             const int u0 = st * S + wv * RB - 2 * R;         // first window row (wave-uniform)

@@ -892,15 +892,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                 asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(angle_bins36(fabsf(dx), dy, mag)));
                 const int b = dx < 0.0f ? ORI_BINS - q : q;
                 const float m = (mag * gi) * gj;
-#if !(defined(SIFTMI_ORI_ABL) && SIFTMI_ORI_ABL == 1)
                 lds_add_bits(hist_lds + ((unsigned)b << 2), 0, m);
-#else
-                asm volatile("; histogram add elided" :: "v"(b), "v"(m));
-#endif
             };
-#if defined(SIFTMI_ORI_ABL) && SIFTMI_ORI_ABL == 2               // tools: a keypoint's prologue and tail alone (no sample is visited)
-            if (total < 0)
-#endif
             if (interior && tabled) {
                 // Round 5: an interior window is walked in QUADS, as the descriptor's: four consecutive samples of a window row per lane
                 // and trip (the last quad of a row runs up to three columns past the window: the table's weight there is 0).  The index
@@ -1258,11 +1251,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
         // One sample (x offset fj, y offset i) of the window: SIFTDescriptor.metal:197-222.  gj, gi: gauss(j), gauss(i) (gj = 0 for a
         // candidate that is not a window sample).  INTERIOR (wave-uniform, almost every descriptor): the sample and its four neighbours
         // are inside the image, so the texels come from the walk (wide loads) and there is no per-sample range test or mirror.
-#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 1             // tools: every histogram add elided (the loop without its LDS atomics)
-#define DESC_HADD(a, off, v) asm volatile("; histogram add elided" :: "v"(a), "v"(v))
-#else
 #define DESC_HADD(a, off, v) lds_add_bits((a), (off), (v))
-#endif
         auto sample = [&](auto interior_tag, float fj, int i, float gj, float gi, float t_xp, float t_xm, float t_yp, float t_ym) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
             const float fi = (float)i;
@@ -1454,9 +1443,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 }
             }
         };
-#if defined(SIFTMI_DESC_ABL) && SIFTMI_DESC_ABL == 2             // tools: a descriptor's prologue and epilogue alone (no sample is visited)
-        if (total < 0)
-#endif
         if (interior) walk(std::true_type{}); else walk(std::false_type{});
 #undef DESC_HADD
         if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor

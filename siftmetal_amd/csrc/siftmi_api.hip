@@ -504,6 +504,19 @@ static void t_collect(siftmi_ctx *c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tuning knobs of the measurement tools (tools/README.md: chunk heights, fork widths, workgroup shapes ...).  They are read from the
+// environment ONLY by builds with -DSIFTMI_EXPERIMENT (tools/build_variant.sh); the shipped library compiles every one of them to its
+// default.  (Rounds 2-5 spelled each as its own #ifdef block; the two probes that were more than a knob -- a per-sub-batch timeline of the
+// host-buffer call and a one-phase-per-call split of the step -- are tools/experiments/api_probes_r05.diff.)
+#ifdef SIFTMI_EXPERIMENT
+static long long exp_knob(const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
+static bool exp_set(const char *name) { return getenv(name) != nullptr; }
+#else
+static constexpr long long exp_knob(const char *, long long dflt) { return dflt; }
+static constexpr bool exp_set(const char *) { return false; }
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // launches
 // Rows per chunk of the marching (ring) blur: a workgroup walks its 128-column strip down one chunk in steps of 32 rows and
 // pays 2R extra horizontally blurred rows for the chunk's prologue (20 % of a 128-row chunk at R = 13).  Tall octaves take
@@ -512,10 +525,7 @@ static void t_collect(siftmi_ctx *c) {
 // in round 2, 160 since the octave chains of a batch run side by side (round 3: 9.82 against 9.97 ms per step, three interleaved
 // pairs of runs; 192: 10.04).
 static int march_chunk_rows(int h) {
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv(h >= 1600 ? "SIFTMI_EXP_CHUNK_BIG" : "SIFTMI_EXP_CHUNK_SMALL")) return atoi(e);
-#endif
-    return h >= 1600 ? 256 : 160;
+    return (int)exp_knob(h >= 1600 ? "SIFTMI_EXP_CHUNK_BIG" : "SIFTMI_EXP_CHUNK_SMALL", h >= 1600 ? 256 : 160);
 }
 
 // the marching blur is used when its grid has at least this many workgroups (cfg.blur_march_min_blocks, default 800 = about one
@@ -531,10 +541,7 @@ static bool uses_march(const siftmi_ctx *c, int w, int h, int nf) {
 // EXPERIMENT: unused dynamic LDS added to every ring launch (fewer resident ring workgroups per CU, so that another stream's
 // keypoint kernels find LDS and wave slots beside them)
 static size_t ring_pad_lds() {
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_RING_PAD_LDS")) return (size_t)atoll(e);
-#endif
-    return 0;
+    return (size_t)exp_knob("SIFTMI_EXP_RING_PAD_LDS", 0);
 }
 
 template <int R, bool SEED, bool DEC>
@@ -553,9 +560,7 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
         if (R >= 9) {
             const long long total_long = (long long)((w + Gr::TW - 1) / Gr::TW) * ((h + 543) / 544) * nf;
             bool long_ok = total_long >= 1536;
-#ifdef SIFTMI_EXPERIMENT
-            long_ok = long_ok && getenv("SIFTMI_EXP_CHUNK_BIG") == nullptr && getenv("SIFTMI_EXP_CHUNK_SMALL") == nullptr;
-#endif
+            long_ok = long_ok && !exp_set("SIFTMI_EXP_CHUNK_BIG") && !exp_set("SIFTMI_EXP_CHUNK_SMALL");
             if (long_ok) chr = 544;
         }
         const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
@@ -574,9 +579,7 @@ static hipError_t launch_blur_rd(siftmi_ctx *c, hipStream_t st, const float *src
         // settings keep the tile kernel): longer chunks, because its prologue runs the luma / upscale expansion twice
         // (round 4, 64 x 1080p: 128 / 192 / 256 / 384 / 544 / 1088 / 2176-row chunks 0.739 / 0.724 / 0.671-0.688 / 0.655 / 0.659 / 0.651 / 0.685 ms)
         int chr = h >= 1600 ? 544 : 256;
-#ifdef SIFTMI_EXPERIMENT
-        if (const char *e = getenv("SIFTMI_EXP_SEED_CHUNK")) chr = atoi(e);
-#endif
+        chr = (int)exp_knob("SIFTMI_EXP_SEED_CHUNK", chr);
         const int total = ((w + Gr::TW - 1) / Gr::TW) * ((h + chr - 1) / chr) * nf;
         if (uses_march(c, w, h, nf)) {
             march = true;
@@ -654,9 +657,7 @@ static int chain_tile(const siftmi_ctx *c, int o, int nf) {            // 0 = th
 // 1920x1080 frame: octave 0's scan is 50-70 us of full rows against the ~10 % the flags add to three of its layers)
 static bool tile_flags(const siftmi_ctx *c, int o, int nf) {
     long long min_px = 1500000;
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_TILE_ACT_MIN_PX")) min_px = atoll(e);
-#endif
+    min_px = exp_knob("SIFTMI_EXP_TILE_ACT_MIN_PX", min_px);
     return (long long)c->ow[o] * c->oh[o] * nf >= min_px;
 }
 template <int T, int NTHR, int RA, int RB, int RC>
@@ -680,10 +681,7 @@ static hipError_t launch_blur_chain(siftmi_ctx *c, hipStream_t st, float *layer0
 
 // A descriptor gets a whole workgroup on launches of at most this many octave-0 pixels ("a frame or two")
 static long long small_launch_pixels() {
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_COOP_PX")) return atoll(e);
-#endif
-    return 16ll * 1024 * 1024;
+    return exp_knob("SIFTMI_EXP_COOP_PX", 16ll * 1024 * 1024);
 }
 // The captured launch sequence forks into one chain per octave (run_dense_detect) unless a single frame's first octave is larger
 // than this.  Round 2 forked only "a frame or two" (<= 16 Mpixel per launch); measured in round 3 (tools/batch_size_sweep.py,
@@ -692,9 +690,7 @@ static long long small_launch_pixels() {
 // 12.0 -> 10.8 ms; one 8192 x 8192 tile (268 Mpixel first octave) 6.4 -> 6.6 ms, hence the cap per frame.
 static bool fork_chains(const siftmi_ctx *c) {
     long long max_px = 48ll * 1024 * 1024;
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_FORK_PX")) max_px = atoll(e);
-#endif
+    max_px = exp_knob("SIFTMI_EXP_FORK_PX", max_px);
     if (c->cfg.graph_fork) return c->n_oct > 1 && c->cfg.graph_fork > 0;
     return c->n_oct > 1 && (long long)c->ow[0] * c->oh[0] <= max_px && !c->dense_hint;
 }
@@ -734,9 +730,7 @@ static int launch_extrema(siftmi_ctx *c, hipStream_t st, int nf, int o) {
     }
     t_begin(c, SIFTMI_T_EXTREMA);
     int wpb = 4;
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_EXT_WPB")) wpb = atoi(e);
-#endif
+    wpb = (int)exp_knob("SIFTMI_EXP_EXT_WPB", wpb);
     const int cols_per_wg = (wpb == 1 ? 1 : 4) * EXT_COLS_PER_WAVE;
     dim3 grid((c->ow[o] - 2 + cols_per_wg - 1) / cols_per_wg, (c->oh[o] - 2 + EH - 1) / EH, nf);
     const unsigned char *actp = c->act_valid[o] ? c->d_act + c->act_off[o] : nullptr;
@@ -805,9 +799,7 @@ static int run_dense_detect(siftmi_ctx *c, hipStream_t st, int nf, const void *d
     hipStream_t cur = st;
     bool joined[MAX_OCT] = {};
     int fork_width = 0;                                       // chains a forked sequence may use (0: one per octave)
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_FORK_WIDTH")) fork_width = atoi(e);
-#endif
+    fork_width = (int)exp_knob("SIFTMI_EXP_FORK_WIDTH", fork_width);
     for (int o = 0; o < c->n_oct; o++) {
         hipStream_t next = cur;
         const bool fork_here = fork && o + 1 < c->n_oct && (fork_width == 0 || o + 1 < fork_width);
@@ -916,11 +908,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     // until the slowest was done; keypoints and descriptors differ 4x in window size.  Measured, 64 x 1080p: descriptors 1.20 -> 1.04 ms
     // on the benchmark frames, 6.46 -> 6.2 ms on dense texture (tools/dense_stage_times.py); the records do not depend on it.
     int wpb_ori = 1, wpb_desc = 1, wg1 = 1024;                // workgroups per (frame, octave) group of the one-wavefront forms
-#ifdef SIFTMI_EXPERIMENT
-    if (const char *e = getenv("SIFTMI_EXP_KP_WG")) wg1 = atoi(e);
-    if (const char *e = getenv("SIFTMI_EXP_ORI_WPB")) wpb_ori = atoi(e);
-    if (const char *e = getenv("SIFTMI_EXP_DESC_WPB")) wpb_desc = atoi(e);
-#endif
+    wg1 = (int)exp_knob("SIFTMI_EXP_KP_WG", wg1); wpb_ori = (int)exp_knob("SIFTMI_EXP_ORI_WPB", wpb_ori); wpb_desc = (int)exp_knob("SIFTMI_EXP_DESC_WPB", wpb_desc);
     if (coop)
         hipLaunchKernelGGL((orientation_kernel<true, 4>), dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                            c->d_ori_angles);
@@ -1049,15 +1037,7 @@ static int enqueue_batch(siftmi_ctx *c, hipStream_t st, int32_t n_frames, const 
     for (int f0 = 0; f0 < n_frames; f0 += c->B) {
         const int nf = std::min(c->B, n_frames - f0);
         const unsigned char *px = (const unsigned char *)d_pixels + (size_t)f0 * frame_stride;
-#ifdef SIFTMI_EXPERIMENT                                   // tools/phase_experiment.py: one phase of the step per call
-        const char *ph = getenv("SIFTMI_EXP_PHASE");
-        const int phase = ph ? atoi(ph) : 0;
-        if (phase != 2)
-#endif
         if ((rc = run_dense_detect(c, st, nf, px, format, row_stride, frame_stride, fork, f0 == 0))) return rc;
-#ifdef SIFTMI_EXPERIMENT
-        if (phase == 1) continue;
-#endif
         if (!fork) {                                       // forked: the per-octave chains ran them (run_dense_detect)
             if ((rc = run_refine(c, st, nf, -1))) return rc;
             if ((rc = run_describe(c, st, nf, -1))) return rc;
@@ -1306,20 +1286,11 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
     }
     if (!c->d2h_stream) HIP_TRY(create_copy_stream(&c->d2h_stream));
     int sub = 0;
-#ifdef SIFTMI_EXPERIMENT
-    static const bool tl_on = getenv("SIFTMI_EXP_TIMELINE") != nullptr;
-    std::vector<hipEvent_t> tl_h2d, tl_comp;
-    hipEvent_t tl_t0 = nullptr;
-    if (tl_on) { (void)hipEventCreate(&tl_t0); (void)hipEventRecord(tl_t0, st); }
-#endif
     for (int f0 = 0, nf = 0; f0 < n_frames; f0 += nf, sub++) {
         nf = std::min(f0 == 0 ? first_nf : c->B, n_frames - f0);
         const void *d_px; size_t d_row, d_frame;
         const unsigned char *src = (const unsigned char *)pixels + (size_t)f0 * frame_stride;
         if ((rc = stage_input(c, nf, src, format, row_stride, frame_stride, on_device, &d_px, &d_row, &d_frame))) return rc;
-#ifdef SIFTMI_EXPERIMENT
-        if (tl_on && !on_device) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->copy_stream); tl_h2d.push_back(e); }
-#endif
         // The launch sequence of a sub-batch is captured and replayed like a device-resident call's (round 4: until then this entry
         // issued ~40 direct launches per sub-batch on one chain): its signature is the staging slot (or the caller's device
         // frames), the sub-batch's place in the call and the context's own output buffers, so repeated calls of one shape
@@ -1342,9 +1313,7 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
         // call forked, 14.8-16.0 one chain; with the copy streams on hardware queues of their own -- SIFTMI_COPY_STREAM_PRIORITY=1
         // -- 16.4-16.7 forked).
         bool host_fork = false;
-#ifdef SIFTMI_EXPERIMENT
-        host_fork = getenv("SIFTMI_EXP_HOST_FORK") != nullptr;
-#endif
+        host_fork = exp_set("SIFTMI_EXP_HOST_FORK");
         auto enqueue_g = [&](bool fork) { return enqueue(fork && (on_device != 0 || host_fork)); };
         if ((rc = replay_or_capture(c, st, key, enqueue_g, &launched))) return rc;
         if (!launched) {
@@ -1356,9 +1325,6 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
         // the running totals after this sub-batch: its packed records are final from here on
         HIP_TRY(hipMemcpyAsync(c->h_sub.data() + 4 * sub, c->d_state, sizeof(PackState), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(c->ev_sub[(size_t)sub], st));
-#ifdef SIFTMI_EXPERIMENT
-        if (tl_on) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); tl_comp.push_back(e); }
-#endif
         c->last_sub_frames = nf;
     }
     const size_t ng = (size_t)n_frames * c->n_oct;
@@ -1388,22 +1354,6 @@ extern "C" int siftmi_detect_describe_batch(siftmi_ctx *c, int32_t n_frames, con
         if (ps.total_desc) HIP_TRY(hipMemcpyAsync(c->h_desc.data(), c->d_out_desc, (size_t)ps.total_desc * sizeof(DescriptorRec), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-#ifdef SIFTMI_EXPERIMENT
-    if (tl_on) {
-        (void)hipDeviceSynchronize();
-        fprintf(stderr, "timeline (ms after the call's first stream operation): ");
-        for (size_t i = 0; i < tl_comp.size(); i++) {
-            float a = 0, b = 0;
-            if (i < tl_h2d.size()) (void)hipEventElapsedTime(&a, tl_t0, tl_h2d[i]);
-            (void)hipEventElapsedTime(&b, tl_t0, tl_comp[i]);
-            fprintf(stderr, "[sub %zu: upload done %.2f, kernels done %.2f] ", i, a, b);
-        }
-        fprintf(stderr, "\n");
-        for (hipEvent_t e : tl_h2d) (void)hipEventDestroy(e);
-        for (hipEvent_t e : tl_comp) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(tl_t0);
-    }
-#endif
     t_collect(c);
     c->last_frames = n_frames;
     c->pyramid_valid = true;

@@ -1,4 +1,5 @@
-"""Experiment (library built with -DSIFTMI_EXPERIMENT, SIFTMI_LIB pointing at it): the dense phase (seed, pyramid, extrema)
+"""(needs the SIFTMI_EXP_PHASE probe: `patch -p0 < tools/experiments/api_probes_r05.diff` before building the -DSIFTMI_EXPERIMENT variant)
+Experiment (library built with -DSIFTMI_EXPERIMENT, SIFTMI_LIB pointing at it): the dense phase (seed, pyramid, extrema)
 and the keypoint phase (refine ... pack) of a step as separate calls on separate streams, the keypoint stream restricted to
 a subset of the CUs (hipExtStreamCreateWithCUMask), so that the VALU-bound keypoint kernels cannot take the whole chip from
 the other context's HBM-bound dense kernels.  No torch.

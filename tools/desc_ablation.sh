@@ -1,5 +1,6 @@
 #!/bin/bash
-# descriptor-kernel ablations on dense frames (tools/build_variant.sh abl1|abl2|abl3, -DSIFTMI_DESC_ABL=n): stage times
+# descriptor-kernel ablations on dense frames: stage times of every variant library under tools/tmp_variants (tools/build_variant.sh).
+# The -DSIFTMI_DESC_ABL=n / -DSIFTMI_ORI_ABL=n hooks are kept as tools/experiments/sample_loop_ablations_r06.diff (apply with patch -p0).
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 for V in "" $(ls tools/tmp_variants/*.so 2>/dev/null); do

@@ -1,4 +1,5 @@
-"""Experiment (library built with -DSIFTMI_EXPERIMENT, SIFTMI_LIB pointing at it): can the vector-bound keypoint phase of step k
+"""(needs the SIFTMI_EXP_PHASE probe: `patch -p0 < tools/experiments/api_probes_r05.diff` before building the -DSIFTMI_EXPERIMENT variant)
+Experiment (library built with -DSIFTMI_EXPERIMENT, SIFTMI_LIB pointing at it): can the vector-bound keypoint phase of step k
 (refine ... pack) run INSIDE the load/store-bound dense phase (seed, pyramid, scan) of step k + 1?  Two large kernels on two hardware
 queues take turns (profiles/cumask_dense_r05.log: the strict two-stream schedule costs the SUM of the phases), so here the orientation
 and descriptor kernels are launched as a FEW wavefronts per CU over all (frame, octave) groups (SIFTMI_EXP_KP_FLAT = wavefronts per CU;

@@ -115,23 +115,27 @@ static void bench_R(Ctx &c, float rho) {
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("ring S=" #S_ " rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_ " HPIPE", c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, H8_, true>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
     VRP(32, 256, 3, true) VRP(32, 256, 2, true)
+    // (round 3's vertical pass on the matrix cores needs tools/experiments/blur_mfma_vertical_r03.diff applied to dense_kernels.hip.h:
+    // build with -DBLUR_VARIANTS_WITH_VM after `patch -p0 < tools/experiments/blur_mfma_vertical_r03.diff`)
+#ifdef BLUR_VARIANTS_WITH_VM
     // round 3: the vertical pass on the matrix cores (VM): v_mfma_f32_4x4x1 (16 blocks) per window row against the banded tap matrix
 #define VRM(S_, CHR_, MINW_, H8_, HP_, VM_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         run_variant("ring VM=" #VM_ " (MFMA vertical pass) rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_ " HPIPE=" #HP_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 0, -1, H8_, HP_, VM_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, noact, none); }); }
     VRM(32, 256, 4, (R <= 12), false, 1) VRM(32, 256, 3, true, false, 1) VRM(32, 256, 4, (R <= 12), false, 2) VRM(32, 256, 3, true, false, 2) VRM(32, 256, 3, true, true, 2) VRM(32, 128, 3, true, false, 2)
+#endif
 #define VRMD(S_, CHR_, MINW_, H8_, VM_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
         const int total = tx * nch * c.nf; dim3 grid(((total + 7) / 8) * 8, 1, 1); \
         Activity dbg{(unsigned char *)c.diag, 0, 0, 0.0f}; \
         CHECK(hipMemset(c.diag, 0, (size_t)grid.x * 4 * 8 * 8)); \
-        run_variant("stamps rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_ " VM=" #VM_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 1, -1, H8_, false, VM_>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, dbg, none); }); \
+        run_variant("stamps rows/chunk=" #CHR_ " minw=" #MINW_ " H8=" #H8_ " VM=" #VM_, c, R, [&] { hipLaunchKernelGGL((blur_ring_kernel<R, MINW_, S_, false, false, 1, -1, H8_, false>), grid, dim3(256), G::lds_bytes, 0, c.src, c.dst, c.w, c.h, c.n, c.n, wt, c.nf, CHR_, nodec, dbg, none); }); \
         { std::vector<unsigned long long> d((size_t)total * 32); CHECK(hipMemcpy(d.data(), c.diag, d.size() * 8, hipMemcpyDeviceToHost)); \
             double sum[8] = {0}; for (size_t i = 0; i < d.size(); i++) sum[i & 7] += (double)d[i]; double tot = 0; for (int k = 0; k < 8; k++) tot += sum[k]; \
             const char *nm[8] = {"issue", "H", "B2wait", "V", "stores", "B3wait", "vmwait+ldsw", "B1wait"}; \
             printf("      stamps (cycles per wave-step, share):"); for (int k = 0; k < 8; k++) printf(" %s %.0f (%.0f%%)", nm[k], sum[k] / ((double)tx * c.nf * ((c.h + S_ - 1) / S_) * 4 * 24) , 100.0 * sum[k] / tot); printf("\n"); } }
-    VRMD(32, 256, 4, (R <= 12), 0) VRMD(32, 256, 4, (R <= 12), 1) VRMD(32, 256, 3, true, 2)
+    VRMD(32, 256, 4, (R <= 12), 0)
     // occupancy sensitivity: the same kernel with 12 KB of unused dynamic LDS (3 instead of 4 workgroups per CU at R <= 8, 2 instead of 3 above)
 #define VRL(S_, CHR_, MINW_) { using G = RingGeom<R, S_>; \
         const int tx = (c.w + G::TW - 1) / G::TW, nch = (c.h + CHR_ - 1) / CHR_; \
