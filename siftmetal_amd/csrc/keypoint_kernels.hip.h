@@ -902,23 +902,29 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 const int qpr = (side + 3) >> 2, total_q = side * qpr;
                 const float inv_qpr = 1.0f / (float)qpr;
-                for (int q = lidx; q < total_q; q += STRIDE) {
-                    const int jj = (int)(((float)q + 0.5f) * inv_qpr), k4 = (q - jj * qpr) << 2;
-                    const int c = __mul24(y + jj - r - 1, g.pitch) + ((x + k4 - r - 1) << 2);     // texel (x + i0 - 1, y + j - 1), i0 = k4 - r, j = jj - r
-                    const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);           // row y + j: columns x + i0 - 1 ... + 2
-                    const u32x2 rb = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);       //            ... + 3, + 4
-                    const u32x4 ru = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);             // row y + j - 1: columns x + i0 ... + 3
-                    const u32x4 rd = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);   // row y + j + 1
-                    const float gj = otab[jj];
-                    const float *gq = otab + k4;
+                struct Quad { u32x4 ra, ru, rd; u32x2 rb; int jj, k4; };
+                auto fetch = [&](int q, Quad &t) {
+                    t.jj = (int)(((float)q + 0.5f) * inv_qpr); t.k4 = (q - t.jj * qpr) << 2;
+                    const int c = __mul24(y + t.jj - r - 1, g.pitch) + ((x + t.k4 - r - 1) << 2);  // texel (x + i0 - 1, y + j - 1), i0 = k4 - r, j = jj - r
+                    t.ra = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c, g.pitch, 0);           // row y + j: columns x + i0 - 1 ... + 2
+                    t.rb = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, c + 16, g.pitch, 0);       //            ... + 3, + 4
+                    t.ru = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 0, 0);             // row y + j - 1: columns x + i0 ... + 3
+                    t.rd = __builtin_amdgcn_raw_buffer_load_b128(g.rsrc, c + 4, 2 * g.pitch, 0);   // row y + j + 1
+                };
+                auto consume = [&](const Quad &t) {
+                    const float gj = otab[t.jj];
+                    const float *gq = otab + t.k4;
                     const float G[4] = {gq[0], gq[1], gq[2], gq[3]};
-                    const float A[6] = {__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w),
-                                        __uint_as_float(rb.x), __uint_as_float(rb.y)};
-                    const float U[4] = {__uint_as_float(ru.x), __uint_as_float(ru.y), __uint_as_float(ru.z), __uint_as_float(ru.w)};
-                    const float D[4] = {__uint_as_float(rd.x), __uint_as_float(rd.y), __uint_as_float(rd.z), __uint_as_float(rd.w)};
+                    const float A[6] = {__uint_as_float(t.ra.x), __uint_as_float(t.ra.y), __uint_as_float(t.ra.z), __uint_as_float(t.ra.w),
+                                        __uint_as_float(t.rb.x), __uint_as_float(t.rb.y)};
+                    const float U[4] = {__uint_as_float(t.ru.x), __uint_as_float(t.ru.y), __uint_as_float(t.ru.z), __uint_as_float(t.ru.w)};
+                    const float D[4] = {__uint_as_float(t.rd.x), __uint_as_float(t.rd.y), __uint_as_float(t.rd.z), __uint_as_float(t.rd.w)};
 #pragma unroll
                     for (int s4 = 0; s4 < 4; s4++) accumulate(A[s4 + 2] - A[s4], D[s4] - U[s4], G[s4], gj);
-                }
+                };
+                // (No software pipelining: requesting the next trip's texels before this trip's are used costs 14 registers, the kernel then
+                // spills, 1.26 -> 3.4-4.2 ms on dense frames: profiles/desc_variants_r06.log.)
+                for (int q = lidx; q < total_q; q += STRIDE) { Quad t; fetch(q, t); consume(t); }
             } else {
                 // windows that touch the image border (mirror edges; outside the image -> gradient (0, 0)), or wider than the table
                 for (int idx = lidx; idx < total; idx += STRIDE) {
