@@ -124,13 +124,39 @@ __global__ __launch_bounds__(256) void match_prep_kernel(const DescriptorRec *__
     if (i < n && k == 0) norm[i] = nb;
 }
 
+// FUSED (round 6): the whole match as ONE launch, for calls of the sizes the path produces (two frames' descriptors: a few thousand a
+// side; up to 128 source groups).  Rounds 3-5 ran prep -> this kernel -> finalize (-> compaction): at 2.5 k x 2.3 k that is four
+// dependent launches of 5-8 us around 2 us of matrix work.  With FUSED
+//   * the operands come straight from the descriptor records (136-byte stride, features at byte 8): re-biased in registers on their
+//     way into the B fragments / the LDS tile, norms summed in the same pass (match_prep_kernel's arithmetic, dword for dword);
+//   * the LAST block of a source group to finish (a ticket per group) combines the group's splits in target order, applies the
+//     thresholds (match_finalize_kernel's arithmetic), writes the per-source records and -- for the device-resident call -- packs the
+//     matched ones in source order: every group publishes its match count under the call's epoch, a group adds up the counts of the
+//     groups before it (one thread per earlier group polls; no chain) and writes its matches behind them; the last group writes the total.
+// Same keys, same ordered combine, same thresholds: identical indices (tests/test_gpu_parity.py::test_match_*).
+// A group's last block waits only for blocks that are already running or will be dispatched into slots other blocks free (at most one
+// block per group ever waits: <= 128 of 512 resident).
+struct MatchTail {
+    float abs_thr, rel_thr;
+    MatchRec *out;                     // one record per source (target -1: no match)
+    MatchRec *packed;                  // or null: the matched records in source order
+    int32_t *count;                    // their number (with `packed`)
+    unsigned *ticket;                  // [groups], zero between calls (the last block of a group resets its own)
+    unsigned long long *status;        // [groups]: epoch << 32 | matches of the group
+    unsigned epoch;                    // of this call; never 0
+};
+typedef int i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte piece of a descriptor record: dword-aligned only
+
 // amdgpu_waves_per_eu(2): caps the kernel at 256 VGPRs, which makes the compiler keep the MFMA results in VGPRs
 // (no v_accvgpr_read per element in the scan).
+template <bool FUSED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM_WAVES_DEF, MM_WAVES_DEF)))
-void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int *__restrict__ tgt_packed,
-                       const int *__restrict__ tgt_norm, int n_tgt, int split_len /* multiple of MM_SPLIT_QUANTUM */,
+void match_mfma_kernel(const int *__restrict__ src_packed /* FUSED: the source DescriptorRec array */, int n_src,
+                       const int *__restrict__ tgt_packed /* FUSED: the target DescriptorRec array */,
+                       const int *__restrict__ tgt_norm /* FUSED: unused */, int n_tgt, int split_len /* multiple of MM_SPLIT_QUANTUM */,
                        int4 *__restrict__ part /* [gridDim.y][n_src]: best, idx, second */,
-                       const int4 *__restrict__ bound /* or null: [n_src] records of a pre-pass over targets [0, P), P <= split_len */) {
+                       const int4 *__restrict__ bound /* or null: [n_src] records of a pre-pass over targets [0, P), P <= split_len */,
+                       MatchTail tail = MatchTail{}) {
     constexpr bool XPF = MM_XPF_DEF && MM_PIPE_DEF && MM_TT == 2;
     constexpr int NBUF = XPF ? 3 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[NBUF][MM_TT][32 * MM_ROW];
@@ -141,12 +167,28 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
     const int t_lo = blockIdx.y * split_len, t_hi = min(n_tgt, t_lo + split_len);
     // sources of this wave: B operands, resident
     i32x4 b[MM_NB][4];
+    int src_nrm[MM_NB];                                      // FUSED: sum (f - 128)^2 of this lane's source (the finalize step's per-source constant)
     const int s0 = blockIdx.x * MM_SRC_PER_BLOCK + wv * (32 * MM_NB);
 #pragma unroll
     for (int nb = 0; nb < MM_NB; nb++) {
         const int sc = min(s0 + nb * 32 + c, n_src - 1);
+        src_nrm[nb] = 0;
 #pragma unroll
-        for (int m = 0; m < 4; m++) b[nb][m] = *reinterpret_cast<const i32x4 *>(src_packed + (long long)sc * 32 + m * 8 + h * 4);
+        for (int m = 0; m < 4; m++) {
+            if (FUSED) {
+                const unsigned char *rp = reinterpret_cast<const unsigned char *>(src_packed) + (size_t)sc * sizeof(DescriptorRec) + 8 + m * 32 + h * 16;
+                const i32x4 f = *reinterpret_cast<const i32x4_a4 *>(rp);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int v = f[e] ^ (int)0x80808080;                     // f - 128 per byte, signed
+                    b[nb][m][e] = ~v;                                        // 127 - f (match_prep_kernel)
+                    src_nrm[nb] = dot4(v, v, src_nrm[nb]);
+                }
+            } else {
+                b[nb][m] = *reinterpret_cast<const i32x4 *>(src_packed + (long long)sc * 32 + m * 8 + h * 4);
+            }
+        }
+        if (FUSED) src_nrm[nb] += __shfl_xor(src_nrm[nb], 32, 64);           // the other half of every 32-byte slice
     }
     // staging role of this thread: tile row r (MFMA row), 16-byte piece p, of each of the MM_TT tiles
     const int r = tid >> 3, p = tid & 7, hr = (r >> 2) & 1, pos = (r >> 3) * 4 + (r & 3);
@@ -157,6 +199,20 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
         for (int j = 0; j < MM_TT; j++) {
             const int t = st_base + (it * MM_TT + j) * 16;
             const bool valid = t < st_end;
+            if (FUSED) {
+                const unsigned char *rp = reinterpret_cast<const unsigned char *>(tgt_packed) + (size_t)(valid ? t : 0) * sizeof(DescriptorRec) + 8 + p * 16;
+                const i32x4 f = *reinterpret_cast<const i32x4_a4 *>(rp);
+                int nb_ = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int v = f[e] ^ (int)0x80808080;
+                    pre_v[j][e] = v;
+                    nb_ = dot4(v, 0x02020202, dot4(v, v, nb_));              // |v|^2 + 2 sum v = sum (v + 1)^2 - 128 over the row (match_prep_kernel)
+                }
+                nb_ += __shfl_xor(nb_, 1, 64); nb_ += __shfl_xor(nb_, 2, 64); nb_ += __shfl_xor(nb_, 4, 64);   // the row's 8 pieces: lanes 8 k ... 8 k + 7
+                pre_n[j] = (p == 0 && valid) ? nb_ : MM_PAD_NORM;
+                continue;
+            }
             pre_v[j] = *reinterpret_cast<const i32x4 *>(tgt_packed + (long long)(valid ? t : 0) * 32 + p * 4);
             pre_n[j] = MM_PAD_NORM;
             if (p == 0 && valid) pre_n[j] = tgt_norm[t];
@@ -350,10 +406,94 @@ void match_mfma_kernel(const int *__restrict__ src_packed, int n_src, const int 
             const int s = s0 + nb * 32 + c;
             if (s < n_src) {
                 int *q = reinterpret_cast<int *>(part + (long long)blockIdx.y * n_src + s);
-                q[1] = idx[nb]; q[2] = second[nb]; q[3] = 0;
+                if (FUSED) {                                  // every field write-through: the group's last block reads them past its own L2
+                    __hip_atomic_store(q + 1, idx[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(q + 2, second[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    q[1] = idx[nb]; q[2] = second[nb]; q[3] = 0;
+                }
                 __hip_atomic_store(q, best[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through: later splits' blocks read it as a bound
             }
         }
+    }
+    if constexpr (FUSED) {
+        __shared__ int s_last, s_wave_hits[4], s_before[4];
+        // This block's records were stored write-through (device-scope atomic stores go past the XCD's L2) and have been acknowledged once
+        // vmcnt is 0; then the ticket.  No release fence: at device scope that is a write-back of the whole L2 (buffer_wbl2), tens of
+        // microseconds per block, for three dwords per source that never sat in it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = atomicAdd(&tail.ticket[blockIdx.x], 1u);
+            s_last = t == gridDim.y - 1;
+            if (s_last) tail.ticket[blockIdx.x] = 0u;        // (nobody else touches it before the next call)
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // the group's 512 sources: lane (wave wv, column c, half 0) finishes sources s0 + nb 32 + c -- in source order that is (wv, nb, c)
+        const int n_split = gridDim.y;
+        MatchRec rec[MM_NB];
+        unsigned hits = 0;                                   // bit nb: source nb of this lane matched
+        int wave_hits = 0, lane_before[MM_NB];
+#pragma unroll
+        for (int nb = 0; nb < MM_NB; nb++) {
+            const int s = s0 + nb * 32 + c;
+            const bool live = h == 0 && s < n_src;
+            int fb = MM_NONE, fi = -1, fs = MM_NONE;
+            if (live) {
+                // splits combine in target order (match_finalize_kernel); eight splits' records requested together (device-scope loads:
+                // the other blocks' records are read past this XCD's L2, which may hold the lines of an earlier call)
+                for (int k0 = 0; k0 < n_split; k0 += 8) {
+                    int qb[8], qi[8], qs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int *q = reinterpret_cast<const int *>(part + (long long)min(k0 + j, n_split - 1) * n_src + s);
+                        qb[j] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        qi[j] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        qs[j] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (k0 + j < n_split && qb[j] < fb) { fs = min(fb, qs[j]); fb = qb[j]; fi = qi[j]; }
+                }
+            }
+            rec[nb].source = s; rec[nb].target = -1; rec[nb].distance = 0.0f;
+            if (fi >= 0) {
+                const float bd = sqrtf((float)(fb + src_nrm[nb])) / 255.0f;
+                const float sd = (fs == MM_NONE) ? 3.402823466e+38f : sqrtf((float)(fs + src_nrm[nb])) / 255.0f;
+                rec[nb].distance = bd;
+                if (bd < tail.abs_thr && bd < sd * tail.rel_thr) rec[nb].target = fi;
+            }
+            if (live) tail.out[s] = rec[nb];
+            const bool hit = live && rec[nb].target >= 0;
+            const unsigned long long bal = __ballot(hit);
+            lane_before[nb] = wave_hits + __popcll(bal & ((1ull << lane) - 1ull));
+            wave_hits += __popcll(bal);
+            hits |= hit ? (1u << nb) : 0u;
+        }
+        if (tail.packed == nullptr) return;
+        if (lane == 0) s_wave_hits[wv] = wave_hits;
+        __syncthreads();
+        const int group_hits = s_wave_hits[0] + s_wave_hits[1] + s_wave_hits[2] + s_wave_hits[3];
+        if (tid == 0)
+            __hip_atomic_store(&tail.status[blockIdx.x], ((unsigned long long)tail.epoch << 32) | (unsigned)group_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // matches of the groups before this one: thread t polls group t's count of THIS call (<= 128 groups: one round)
+        int before = 0;
+        for (int g = tid; g < (int)blockIdx.x; g += 256) {
+            unsigned long long v;
+            do { v = __hip_atomic_load(&tail.status[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(v >> 32) != tail.epoch);
+            before += (int)(unsigned)v;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o, 64);
+        if (lane == 0) s_before[wv] = before;
+        __syncthreads();
+        int pos = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+        for (int k = 0; k < wv; k++) pos += s_wave_hits[k];
+#pragma unroll
+        for (int nb = 0; nb < MM_NB; nb++)
+            if (hits & (1u << nb)) tail.packed[pos + lane_before[nb]] = rec[nb];
+        if (blockIdx.x == gridDim.x - 1 && tid == 0) *tail.count = s_before[0] + s_before[1] + s_before[2] + s_before[3] + group_hits;
     }
 }
 

@@ -166,6 +166,8 @@ struct siftmi_ctx {
     DescriptorRec *d_match_src = nullptr, *d_match_tgt = nullptr; long long match_src_cap = 0, match_tgt_cap = 0;
     MatchRec *d_match_out = nullptr; long long match_out_cap = 0;
     int *d_match_scratch = nullptr; long long match_scratch_cap = 0;
+    unsigned char *d_match_sync = nullptr;     // the fused matcher's per-group tickets (u32) and counts (u64): zeroed once, self-resetting / epoch-tagged
+    unsigned match_epoch = 0;
     int last_frames = 0;                      // frames of the last batch call
     int last_sub_frames = 0;                  // frames resident in the pyramid
     bool pyramid_valid = false;
@@ -283,7 +285,7 @@ static void free_ctx(siftmi_ctx *c) {
     void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_bucket_keys, c->d_bucket_src, c->d_row_count,
                     c->d_row_start, c->d_act, c->d_ori_count, c->d_ori_angles,
                     c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_out_kp,
-                    c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out, c->d_match_scratch};
+                    c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out, c->d_match_scratch, c->d_match_sync};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1537,8 +1539,12 @@ extern "C" int siftmi_match_plan(int64_t n_source, int64_t n_target, int64_t *sp
 }
 
 // The matcher's launch sequence on `st`: leaves one record per source (target -1 = no match) in c->d_match_out.  d_src / d_tgt: device memory.
+// d_packed / d_count (the device-resident call): where the matched records and their number go; *packed_done says whether this sequence
+// already wrote them (the fused single-launch form) or the caller still has to compact c->d_match_out (block_count_out).
+constexpr int MM_FUSED_MAX_GROUPS = 128;
 static int enqueue_match(siftmi_ctx *c, hipStream_t st, const DescriptorRec *d_src, int64_t n_source, const DescriptorRec *d_tgt, int64_t n_target,
-                         float absolute_threshold, float relative_threshold, int32_t **block_count_out = nullptr) {
+                         float absolute_threshold, float relative_threshold, int32_t **block_count_out = nullptr, MatchRec *d_packed = nullptr,
+                         int32_t *d_count = nullptr, bool *packed_done = nullptr) {
     auto grow = [&](void **p, long long *cap, long long need, size_t elem) -> int {
         if (need <= *cap) return SIFTMI_OK;
         if (*p) (void)hipFree(*p);
@@ -1551,6 +1557,35 @@ static int enqueue_match(siftmi_ctx *c, hipStream_t st, const DescriptorRec *d_s
     const MatchPlan plan = match_plan(n_source, n_target);
     const long long groups = plan.groups, split_len = plan.split_len, n_split = plan.n_split;
     if (n_split > 65535) return set_error(SIFTMI_E_BADARG, "too many target splits");
+    if (packed_done) *packed_done = false;
+    // Calls of the sizes the path produces (two frames' descriptors ... ~60 k x 60 k: the unbounded plans): ONE launch (match_mfma_kernel<true>,
+    // match_kernels.hip.h) -- operands straight from the descriptor records, the last block of a source group finalises it and packs its matches.
+    static const bool fused_off = getenv("SIFTMI_MATCH_NO_FUSE") != nullptr;
+    if (!plan.bounded && groups <= MM_FUSED_MAX_GROUPS && !fused_off) {
+        // (Fewer, longer chunks -- so that the tail reads one batch of eight split records instead of three -- were slower: a block's loop is
+        // one memory round trip per 64 targets with one iteration prefetched, 2.5 k x 2.3 k 28.1 against 24.9 us: profiles/match_fused_r06.log.)
+        const long long n_split_f = n_split, split_len_f = split_len;
+        const long long words_f = n_split_f * n_source * 4 + 64;
+        if ((rc = grow((void **)&c->d_match_scratch, &c->match_scratch_cap, words_f, sizeof(int)))) return rc;
+        if ((rc = grow((void **)&c->d_match_out, &c->match_out_cap, n_source, sizeof(MatchRec)))) return rc;
+        if (!c->d_match_sync) {
+            HIP_TRY(hipMalloc((void **)&c->d_match_sync, MM_FUSED_MAX_GROUPS * 16));
+            HIP_TRY(hipMemset(c->d_match_sync, 0, MM_FUSED_MAX_GROUPS * 16));
+        }
+        if (++c->match_epoch == 0) c->match_epoch = 1;
+        MatchTail tail;
+        tail.abs_thr = absolute_threshold; tail.rel_thr = relative_threshold;
+        tail.out = c->d_match_out; tail.packed = d_packed; tail.count = d_count;
+        tail.status = reinterpret_cast<unsigned long long *>(c->d_match_sync);
+        tail.ticket = reinterpret_cast<unsigned *>(c->d_match_sync + MM_FUSED_MAX_GROUPS * 8);
+        tail.epoch = c->match_epoch;
+        hipLaunchKernelGGL(match_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)n_split_f), dim3(256), 0, st, reinterpret_cast<const int *>(d_src), (int)n_source,
+                           reinterpret_cast<const int *>(d_tgt), (const int *)nullptr, (int)n_target, (int)split_len_f, (int4 *)c->d_match_scratch,
+                           (const int4 *)nullptr, tail);
+        HIP_TRY(hipGetLastError());
+        if (packed_done) *packed_done = d_packed != nullptr;
+        return SIFTMI_OK;
+    }
     // scratch: packed int8 rows + norms for both sides, per-split partial results (one allocation)
     const long long n_blocks = (n_source + 255) / 256;
     const long long words = n_source * 33 + n_target * 33 + (n_split + 1) * n_source * 4 + n_blocks + 64;
@@ -1576,11 +1611,11 @@ static int enqueue_match(siftmi_ctx *c, hipStream_t st, const DescriptorRec *d_s
     static_assert(512 % MM_SPLIT_QUANTUM == 0, "the pre-pass is one split of its own");
     if (bounded) {
         HIP_TRY(hipMemsetAsync(part, 0x7f, (size_t)n_split * (size_t)n_source * sizeof(int4), st));   // "none" (0x7f7f7f7f) until a block publishes
-        hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, 1), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
-                           (int)std::min<long long>(n_target, pre_len), (int)pre_len, bound, (const int4 *)nullptr);
+        hipLaunchKernelGGL(match_mfma_kernel<false>, dim3((unsigned)groups, 1), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
+                           (int)std::min<long long>(n_target, pre_len), (int)pre_len, bound, (const int4 *)nullptr, MatchTail{});
     }
-    hipLaunchKernelGGL(match_mfma_kernel, dim3((unsigned)groups, (unsigned)n_split), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
-                       (int)n_target, (int)split_len, part, bounded ? bound : (const int4 *)nullptr);
+    hipLaunchKernelGGL(match_mfma_kernel<false>, dim3((unsigned)groups, (unsigned)n_split), dim3(256), 0, st, src_packed, (int)n_source, tgt_packed, tgt_norm,
+                       (int)n_target, (int)split_len, part, bounded ? bound : (const int4 *)nullptr, MatchTail{});
     hipLaunchKernelGGL(match_finalize_kernel, dim3((unsigned)((n_source + 255) / 256)), dim3(256), 0, st, part, (int)n_split, src_norm, (int)n_source,
                        absolute_threshold, relative_threshold, c->d_match_out, block_count_out ? block_count : (int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
@@ -1645,11 +1680,13 @@ extern "C" int siftmi_match_descriptors_device(siftmi_ctx *c, const siftmi_descr
         return order_end(c, st);
     }
     int32_t *block_count = nullptr;
+    bool packed_done = false;
     if ((rc = enqueue_match(c, st, (const DescriptorRec *)d_source, n_source, (const DescriptorRec *)d_target, n_target, absolute_threshold, relative_threshold,
-                            &block_count))) {
+                            &block_count, (MatchRec *)d_matches, d_count, &packed_done))) {
         (void)order_end(c, st);                                               // whatever was enqueued before the failure stays ordered
         return rc;
     }
+    if (packed_done) return order_end(c, st);                                 // the fused launch packed the matches itself
     const int n_blocks = (int)((n_source + 255) / 256);
     const int prefixed = n_blocks >= 1024 ? 1 : 0;                            // (match_compact_kernel: the in-block sum is quadratic in the block count)
     if (prefixed) hipLaunchKernelGGL(match_block_prefix_kernel, dim3(1), dim3(1024), 0, st, block_count, n_blocks);

@@ -48,16 +48,16 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
         if (prepass) hipMemsetAsync(part, 0x7f, (size_t)n_split * ns * 16, 0);
-        if (prepass) hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, 1), dim3(256), 0, 0, ds, ns, dt, dn, std::min(nt, prepass), prepass, bound, (const int4 *)nullptr);
-        hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prepass ? bound : (const int4 *)nullptr);
+        if (prepass) hipLaunchKernelGGL(match_mfma_kernel<false>, dim3(groups, 1), dim3(256), 0, 0, ds, ns, dt, dn, std::min(nt, prepass), prepass, bound, (const int4 *)nullptr, MatchTail{});
+        hipLaunchKernelGGL(match_mfma_kernel<false>, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prepass ? bound : (const int4 *)nullptr, MatchTail{});
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
 #ifdef MM_COUNT_SLOW
     { unsigned long long z = 0, v = 0; hipMemcpyToSymbol(HIP_SYMBOL(mm_slow_count), &z, 8);
       if (prepass) hipMemset(part, 0x7f, (size_t)n_split * ns * 16);
-      if (prepass) { hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, 1), dim3(256), 0, 0, ds, ns, dt, dn, std::min(nt, prepass), prepass, bound, (const int4 *)nullptr);
+      if (prepass) { hipLaunchKernelGGL(match_mfma_kernel<false>, dim3(groups, 1), dim3(256), 0, 0, ds, ns, dt, dn, std::min(nt, prepass), prepass, bound, (const int4 *)nullptr, MatchTail{});
                      hipDeviceSynchronize(); hipMemcpyToSymbol(HIP_SYMBOL(mm_slow_count), &z, 8); }
-      hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prepass ? bound : (const int4 *)nullptr);
+      hipLaunchKernelGGL(match_mfma_kernel<false>, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, prepass ? bound : (const int4 *)nullptr, MatchTail{});
       hipDeviceSynchronize(); hipMemcpyFromSymbol(&v, HIP_SYMBOL(mm_slow_count), 8);
       const double tiles = (double)groups * n_split * 4 /*waves*/ * MM_NB * (split_len / 2 / 16);
       printf("ordered updates taken: %llu of %.0f (wavefront, 16-target tile, 32-source tile) triples = %.1f %%\n", v, tiles, 100.0 * v / tiles); }
@@ -65,7 +65,7 @@ int main(int argc, char **argv) {
 #ifdef MM_STAMPS
     { unsigned long long z[4] = {0, 0, 0, 0}, v[4]; hipMemcpyToSymbol(HIP_SYMBOL(mm_stamps), z, 32);
       if (prepass) hipMemset(part, 0x7f, (size_t)n_split * ns * 16);
-      hipLaunchKernelGGL(match_mfma_kernel, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, (const int4 *)nullptr);
+      hipLaunchKernelGGL(match_mfma_kernel<false>, dim3(groups, n_split), dim3(256), 0, 0, ds, ns, dt, dn, nt, (int)split_len, part, (const int4 *)nullptr, MatchTail{});
       hipDeviceSynchronize(); hipMemcpyFromSymbol(v, HIP_SYMBOL(mm_stamps), 32);
       const double iters = (double)groups * n_split * 4 * (split_len / 2 / (16 * MM_TT));
       printf("stamps, cycles per wavefront-iteration (%d MFMAs = %d matrix-pipe cycles): prefetch issue %.0f, MFMA groups + screens %.0f, staging %.0f, barrier %.0f\n",
