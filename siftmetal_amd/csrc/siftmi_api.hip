@@ -912,7 +912,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     int wpb_ori = 1, wpb_desc = 1, wg1 = 1024;                // workgroups per (frame, octave) group of the one-wavefront forms
     wg1 = (int)exp_knob("SIFTMI_EXP_KP_WG", wg1); wpb_ori = (int)exp_knob("SIFTMI_EXP_ORI_WPB", wpb_ori); wpb_desc = (int)exp_knob("SIFTMI_EXP_DESC_WPB", wpb_desc);
     if (coop)
-        hipLaunchKernelGGL((orientation_kernel<true, 4>), dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
+        hipLaunchKernelGGL((orientation_kernel<true, 4>), dim3((unsigned)exp_knob("SIFTMI_EXP_COOP_WG", 1024), groups), dim3(256), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
                            c->d_ori_angles);
     else if (wpb_ori == 1)
         hipLaunchKernelGGL((orientation_kernel<false, 1>), dim3(wg1, groups), dim3(64), 0, st, P, c->prm, c->d_kp, cnt(c, C_KP), c->d_ori_count,
@@ -935,7 +935,7 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     t_begin(c, SIFTMI_T_DESCRIBE);
     // a frame or two: fewer descriptors than wavefront slots -> one workgroup per descriptor (see descriptor_kernel)
     if (coop)
-        hipLaunchKernelGGL((descriptor_kernel<true, 4>), dim3(1024, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
+        hipLaunchKernelGGL((descriptor_kernel<true, 4>), dim3((unsigned)exp_knob("SIFTMI_EXP_COOP_WG", 1024), groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
                            c->d_desc_f32);
     else {
         if (wpb_desc == 1 && c->cfg.descriptor_patch_lds)
