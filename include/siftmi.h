@@ -45,8 +45,8 @@ typedef enum siftmi_status {
 /* Pixel formats.  The reference accepts only a .bgra8Unorm texture
    (Metal Compute/ConvertSRGBToGrayscaleKernel.swift:34); GRAY8/GRAYF32 skip the luma step.
    SIFTMI_FMT_GRAYF32 pixels are the luma itself and must lie in [0, 1], the range a unorm texture delivers: thresholds are absolute
-   and the orientation / descriptor histograms are accumulated in 2^-32 fixed point, which saturates for gradients of an
-   unnormalised (0 ... 255, HDR) image.  A frame with a value outside [0, 1] (or a NaN) is reported: SIFTMI_E_BADARG from the
+   and the orientation / descriptor histograms are accumulated in 2^-24 fixed point (u32 bins sized for gradients of a [0, 1] image),
+   which overflows for an unnormalised (0 ... 255, HDR) image.  A frame with a value outside [0, 1] (or a NaN) is reported: SIFTMI_E_BADARG from the
    host-facing entry points, overflow_flags bit 5 on the device path; its results are not to be used. */
 typedef enum siftmi_format {
     SIFTMI_FMT_BGRA8   = 0,

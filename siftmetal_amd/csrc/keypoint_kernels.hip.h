@@ -948,16 +948,33 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
 #pragma unroll
         for (int c = 0; c < OCOPY; c++) hsum += hist0[c * OSTRIDE + li] + (li == 0 ? hist0[c * OSTRIDE + ORI_BINS] : 0u);
         float hv = (float)hsum * ldexpf(1.0f, -24 + 2 * half_shift);
-        const int lm = (li + ORI_BINS - 1) % ORI_BINS, lp = (li + 1) % ORI_BINS;
+        // the circular neighbours of bin `lane` (lanes 0 ... 35): a wavefront shift by one lane (DPP, a vector move) with the wrap-around lane
+        // patched from a v_readlane -- round 6; rounds 1-5 used __shfl, i.e. 14 ds_bpermute round trips through the LDS crossbar per keypoint.
+        // Lanes >= 36 hold values nobody reads.
+        auto prev_bin = [&](float v) -> float {                         // bin (lane - 1) mod 36
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+            const float wrap = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), ORI_BINS - 1));
+            return lane == 0 ? wrap : s;
+        };
+        auto next_bin = [&](float v) -> float {                         // bin (lane + 1) mod 36
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+            const float wrap = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+            return lane == ORI_BINS - 1 ? wrap : s;
+        };
         for (int it = 0; it < prm.ori_smoothing; it++) {               // :67-84
-            const float h0 = __shfl(hv, lm), h2 = __shfl(hv, lp);
+            const float h0 = prev_bin(hv), h2 = next_bin(hv);
             hv = (h0 + hv + h2) / 3.0f;
         }
         float mxv = (lane < ORI_BINS) ? hv : -3.0e38f;                // :44-47 (max is order-free)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, off));
+        {   // wave maximum by DPP (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: lane 63 ends up with it), broadcast through an SGPR
+#define ORI_MAX_DPP(CTRL, ROWMASK) mxv = fmaxf(mxv, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mxv), __builtin_bit_cast(int, mxv), CTRL, ROWMASK, 0xf, false)))
+            ORI_MAX_DPP(0x111, 0xf); ORI_MAX_DPP(0x112, 0xf); ORI_MAX_DPP(0x114, 0xf); ORI_MAX_DPP(0x118, 0xf);
+            ORI_MAX_DPP(0x142, 0xa); ORI_MAX_DPP(0x143, 0xc);
+#undef ORI_MAX_DPP
+            mxv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mxv), 63));
+        }
         const float threshold = prm.ori_threshold * mxv;
-        const float hm = __shfl(hv, lm), hp = __shfl(hv, lp);
+        const float hm = prev_bin(hv), hp = next_bin(hv);
         const bool peak = (lane < ORI_BINS) && (hv > threshold) && (hv > hm) && (hv > hp);
         const unsigned long long mask = __ballot(peak);
         if (peak) {                                                    // :16-33, :52-61
@@ -1063,10 +1080,15 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
     return v;
 }
+// sum over the 64 lanes, the same on every lane: the DPP tree of wave_inclusive_scan (lane 63 ends up with the total) and a v_readlane.
+// (Rounds 1-5: an xor butterfly of six __shfl_xor = six ds_bpermute round trips; the summation order differs, so the normalisation factor of a
+// descriptor can differ from round 5's in its last bit -- every launch form uses this one function.)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+#define WSUM_DPP(CTRL, ROWMASK) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false))
+    WSUM_DPP(0x111, 0xf); WSUM_DPP(0x112, 0xf); WSUM_DPP(0x114, 0xf); WSUM_DPP(0x118, 0xf);
+    WSUM_DPP(0x142, 0xa); WSUM_DPP(0x143, 0xc);
+#undef WSUM_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // COOP = false: one wavefront per descriptor (large launches: there are more descriptors than wavefronts in flight).
@@ -1076,6 +1098,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // WPB = wavefronts per workgroup (COOP = false only): 4, or 1 -- a workgroup's LDS and wave slots are held until its LAST wavefront is
 // done, and descriptors differ 4x in their sample count, so with four independent wavefronts per workgroup a quarter of the slots
 // idles at workgroup tails on dense frames (4.35 of 6 resident, PMC round 4)
+#ifndef SIFTMI_DESC_QCAP
+#define SIFTMI_DESC_QCAP 832                              // entries of the walk's quad table (0: the row-advance walk of round 5)
+#endif
 #ifndef SIFTMI_DESC_WAVES
 #define SIFTMI_DESC_WAVES 7                                // wavefronts per SIMD the descriptor kernel's register budget is sized for (72 VGPRs);
                                                            // the one-wavefront form of large launches: one more (64 VGPRs)
@@ -1120,16 +1145,25 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     // fall into the same cell and bin, and same-address lanes of one LDS add serialise.  The copies of a slot are INTERLEAVED (u32 index
     // = slot * NCOPY + copy, round 3): four neighbouring lanes that hit the same bin then touch four neighbouring banks.
     constexpr int NCOPY = SIFTMI_DESC_NCOPY;
-    constexpr int NSLOT = 9;                               // orientation slots per cell: bins 0 ... 7 and slot 8 = bin 0 again (the upper neighbour of 7)
-    constexpr int HIST = 16 * NSLOT * NCOPY;               // u32 per histogram
+#ifdef SIFTMI_DESC_PACK2
+    // experiment: a slot is a PAIR of u32 -- {contributions to bin fb, contributions to bin fb + 1 from samples whose lower bin is fb} -- so that
+    // a corner is ONE 64-bit LDS add (lo = w va, hi = w vb: neither half can carry, see the bound above); bin b = lo[b] + hi[b - 1]
+    constexpr bool PACK2 = true;
+    constexpr int NSLOT = 8, SLOTW = 2;
+#else
+    constexpr bool PACK2 = false;
+    constexpr int NSLOT = 9, SLOTW = 1;                    // orientation slots per cell: bins 0 ... 7 and slot 8 = bin 0 again (the upper neighbour of 7)
+#endif
+    constexpr int HIST = 16 * NSLOT * NCOPY * SLOTW;       // u32 per histogram
     constexpr int MAXCOL = 128;                            // window columns handled by the compacted walk (2 per lane)
     static_assert(WPB == 4 || (!COOP && WPB == 1), "COOP shares one descriptor among the four wavefronts of a workgroup");
     // One LDS block: per wavefront {weight table, walk tables} first, the histograms after them.  The address of a contribution is that
     // of cell (fx, fy) with fx, fy >= -1 (a corner at -1 is reached through its neighbour at 0 by an immediate offset), i.e. up to 5 NSLOT
     // slots below its histogram: the tables in front keep that address non-negative for the first histogram too.
-    constexpr int QCAP = PATCH ? 0 : 832;                   // quads the walk's quad table holds (a window of the reference's schedule has <= 790)
+    constexpr int QCAP = PATCH ? 0 : SIFTMI_DESC_QCAP;                   // quads the walk's quad table holds (a window of the reference's schedule has <= 790)
     constexpr int TAB_BYTES = ((MAXCOL + 4) * 4 + QCAP * 2 + (MAXCOL + 2) * 2 + MAXCOL + (PATCH ? MAXCOL * 2 : 0) + 15) & ~15;   // gtab, qtab, col_start, col_lo (i8), col_len
-    constexpr int PAD_BYTES = WPB * TAB_BYTES >= 5 * NSLOT * NCOPY * 4 ? 0 : 5 * NSLOT * NCOPY * 4 - WPB * TAB_BYTES;   // (the tables usually are the pad)
+    constexpr int PAD_NEED = 5 * NSLOT * NCOPY * 4 * SLOTW;
+    constexpr int PAD_BYTES = WPB * TAB_BYTES >= PAD_NEED ? 0 : PAD_NEED - WPB * TAB_BYTES;   // (the tables usually are the pad)
     static_assert(TAB_BYTES % 16 == 0 && PAD_BYTES % 16 == 0 && HIST % 4 == 0, "16-byte aligned histograms behind the tables (cleared by 16-byte stores)");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB * TAB_BYTES + PAD_BYTES + WPB * HIST * 4];
     constexpr int TP = 20;                                 // floats per staged tile row (18 used; 80 B keeps a quad's row segment 16-byte aligned)
@@ -1150,7 +1184,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     const int qpos = (lane & ~0x28) | ((lane & 8) << 2) | ((lane & 32) >> 2);
     static_assert(NCOPY == 2 || NCOPY == 4 || NCOPY == 8, "copy = one column bit + block bits");
     const int copy = (qpos & 1) | (((qpos >> 4) & (NCOPY / 2 - 1)) << 1);
-    const float hist_base_f = (float)((unsigned)(size_t)(lds_u32_t *)hist0 + 4u * (unsigned)copy);
+    const float hist_base_f = (float)((unsigned)(size_t)(lds_u32_t *)hist0 + 4u * SLOTW * (unsigned)copy);
     unsigned char *tab = lds_raw + wv * TAB_BYTES;
     float *gtab = reinterpret_cast<float *>(tab);                                        // exp(-k^2 / 8 hw^2) 2^-63 (2^-half_shift folded in), k = -radius ... radius + 3
     unsigned short *qtab = reinterpret_cast<unsigned short *>(tab + (MAXCOL + 4) * 4);   // quad q of the walk: row | (j0 + radius) << 7
@@ -1308,11 +1342,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 // byte address of slot ((fy 4 + fx) NSLOT + fb), this lane's copy: exact in float (garbage where no test passes)
                 const float slot = fmaf(fy, (float)(4 * NSLOT), fmaf(fx, (float)NSLOT, fb));
                 unsigned a;
-                asm("v_cvt_u32_f32 %0, %1" : "=v"(a) : "v"(fmaf(slot, (float)(4 * NCOPY), hist_base_f)));
-                if (xa && ya) { const float wxy = iMin * jMin; DESC_HADD(a, 0, wxy * va); DESC_HADD(a, NCOPY, wxy * vb); }
-                if (xb && ya) { const float wxy = iMax * jMin; DESC_HADD(a, NSLOT * NCOPY, wxy * va); DESC_HADD(a, (NSLOT + 1) * NCOPY, wxy * vb); }
-                if (xb && yb) { const float wxy = iMax * jMax; DESC_HADD(a, 5 * NSLOT * NCOPY, wxy * va); DESC_HADD(a, (5 * NSLOT + 1) * NCOPY, wxy * vb); }
-                if (xa && yb) { const float wxy = iMin * jMax; DESC_HADD(a, 4 * NSLOT * NCOPY, wxy * va); DESC_HADD(a, (4 * NSLOT + 1) * NCOPY, wxy * vb); }
+                asm("v_cvt_u32_f32 %0, %1" : "=v"(a) : "v"(fmaf(slot, (float)(4 * NCOPY * SLOTW), hist_base_f)));
+                auto corner = [&](float wxy, int cell_off) {                 // cell_off: slots from cell (fx, fy) to the corner's cell
+                    if constexpr (PACK2) {
+                        typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+                        const unsigned long long pair = ((unsigned long long)__float_as_uint(wxy * vb) << 32) | __float_as_uint(wxy * va);
+                        __hip_atomic_fetch_add((lds_u64_t *)(size_t)a + cell_off * NCOPY, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        DESC_HADD(a, cell_off * NCOPY, wxy * va); DESC_HADD(a, (cell_off + 1) * NCOPY, wxy * vb);
+                    }
+                };
+                if (xa && ya) corner(iMin * jMin, 0);
+                if (xb && ya) corner(iMax * jMin, NSLOT);
+                if (xb && yb) corner(iMax * jMax, 5 * NSLOT);
+                if (xa && yb) corner(iMin * jMax, 4 * NSLOT);
             }
         };
         auto walk = [&](auto interior_tag) {
@@ -1458,12 +1501,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
         unsigned a0 = 0u, a1 = 0u;
         {
             const int cell = lane >> 3, b = lane & 7;
+            if constexpr (PACK2) {
+                const unsigned *s0 = hist0 + (cell * NSLOT + b) * NCOPY * 2, *s1 = s0 + 8 * NSLOT * NCOPY * 2;
+                const int prev = (((b + 7) & 7) - b) * NCOPY * 2;                   // slot of bin b - 1 (same cell): its high halves belong to bin b
+#pragma unroll
+                for (int c = 0; c < NCOPY; c++) { a0 += s0[2 * c] + s0[prev + 2 * c + 1]; a1 += s1[2 * c] + s1[prev + 2 * c + 1]; }
+            } else {
             const unsigned *s0 = hist0 + (cell * NSLOT + b) * NCOPY, *s1 = s0 + 8 * NSLOT * NCOPY;
 #pragma unroll
             for (int c = 0; c < NCOPY; c++) { a0 += s0[c]; a1 += s1[c]; }
             if (b == 0) {
 #pragma unroll
                 for (int c = 0; c < NCOPY; c++) { a0 += s0[8 * NCOPY + c]; a1 += s1[8 * NCOPY + c]; }
+            }
             }
         }
         const float unit_scale = ldexpf(1.0f, -24 + 2 * half_shift);        // back to the reference's units (the normalisation removes it again)
