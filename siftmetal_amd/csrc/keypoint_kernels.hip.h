@@ -751,16 +751,30 @@ __device__ __forceinline__ float angle_bins36(float y_abs, float x, float m) {
     q = fmaf(q, s, -1.538370371e+00f);
     q = fmaf(q, s, 2.276361704e+00f);
     q = fmaf(q, s, -3.818771601e+00f);
-    // Ties.  The only bin boundaries that gradients of pixel differences hit EXACTLY are 4.5 and 13.5 (|dx| == |dy|), and exactly
-    // symmetric images (checkerboards, 8-bit synthetic patterns) put a large share of their samples on or within an ulp of them.  In the
-    // reference's own f32 expression, round(36 (angle / 2 pi)), pi/4 gives 4.4999995 -> 4 and 3 pi/4 gives 13.5 -> 14.  So the
-    // polynomial fit is PINNED at t = tan(pi / 8) (tools/fit_atan.py 6 pin: zero fit error there, 4.05e-7 rad elsewhere; the f32
-    // evaluation returns 4.5 -5e-7 / +1e-6 for an exact diagonal), and 1e-6 is taken off the acute angle before the reflection (free: the
-    // last multiply becomes an fma), which puts both ties on the reference's side -- emulated against the reference's expression on
-    // 2 M gradients within 3e-6 of the diagonal (same script): 24 of 200 k exact diagonals and 2.7 % of the others fall on the other
-    // side, against every exact diagonal without it.  Every other bin boundary moves by 1.7e-7 rad, inside this function's own error.
-    const float r = fmaf(t, fmaf(s, q, 11.4591559026164642f), -1.0e-6f);
+    const float r = t * fmaf(s, q, 11.4591559026164642f);
     return x < 0.0f ? 18.0f - r : r;
+}
+
+// atan2(y, x) of finite arguments by octant reduction (rounds 2-5's form of every sample; round 6: only the samples next to a 45 / 135 degree
+// boundary of the orientation histogram, see orientation_kernel): quotient by v_rcp_f32, odd degree-17 polynomial (tools/fit_atan.py 8),
+// 2.4 ulp / 2.9e-7 rad worst case, and an EXACT diagonal gives t = 1 exactly, i.e. one value whatever the gradient's magnitude.
+__device__ __forceinline__ float atan2_octant(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1.0e-30f));
+    const float s = t * t;
+    float q = 2.622172935e-03f;
+    q = fmaf(q, s, -1.513224095e-02f);
+    q = fmaf(q, s, 4.112136364e-02f);
+    q = fmaf(q, s, -7.366662472e-02f);
+    q = fmaf(q, s, 1.057391018e-01f);
+    q = fmaf(q, s, -1.418596953e-01f);
+    q = fmaf(q, s, 1.999039650e-01f);
+    q = fmaf(q, s, -3.333298564e-01f);
+    float r = fmaf(t, s * q, t);
+    r = ay > ax ? 1.57079632679489662f - r : r;
+    r = x < 0.0f ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -888,9 +902,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
                 // symmetric in the sign of the angle, which is the sign of tx: round the MAGNITUDE (floor(|.| + 0.5), one conversion) and
                 // reflect, 36 - q, for tx < 0 -- exactly diagonal gradients (8-bit synthetic images are full of them) then fall to the same
                 // side as in the reference whatever their quadrant.  q = 0 reflects to slot 36 = bin 0 again.
+                const float a36 = angle_bins36(fabsf(dx), dy, mag);
                 int q;
-                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(angle_bins36(fabsf(dx), dy, mag)));
-                const int b = dx < 0.0f ? ORI_BINS - q : q;
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(a36));
+                int b = dx < 0.0f ? ORI_BINS - q : q;
+                // Next to the 45 / 135 degree boundaries (|a36 - 4.5| or |a36 - 13.5| below 2e-5: never in natural images, 15 % of the samples of
+                // a checkerboard, 3.5 % of them |dx| == |dy| to the bit) the half-angle form is not good enough: its argument carries the errors
+                // of v_sqrt and v_rcp, so EXACT diagonals of different magnitude scatter over both sides of the boundary, the histograms of an exactly
+                // symmetric pattern pick up 1 % noise, and peak counts start to differ from the reference's (profiles/sweep_cases_r06.log).  Those
+                // samples take rounds 2-5's octant form, which maps every exact diagonal to ONE value, and the reference's expression literally.
+                if (fabsf(fabsf(a36 - 9.0f) - 4.5f) < 2.0e-5f) {
+                    b = (int)roundf(atan2_octant(dx, dy) * (float)(ORI_BINS / (2.0 * 3.14159265358979323846)));
+                    if (b < 0) b += ORI_BINS;
+                    if (b >= ORI_BINS) b -= ORI_BINS;
+                }
                 const float m = (mag * gi) * gj;
                 lds_add_bits(hist_lds + ((unsigned)b << 2), 0, m);
             };
@@ -1321,9 +1346,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
             // the wrap is v_fract (which stays below 1: bin < 8)
             const float mag = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, 1.0e-30f)));       // 2 |gradient|, > 0 (angle_turns)
             const float bin = __builtin_amdgcn_fractf(angle_turns(dx, dy, mag) - theta_turns) * 8.0f;
-            // value = |gradient| exp(-(rx^2 + ry^2) / 8) 2^-126: |gradient| = mag / 2, so `v` is the value in units of
-            // 2^-24 2^-149 -- at most sqrt(2) 2^-126, inside the range where a float's bits are linear in its value
-            const float v = (mag * gj) * gi;
+            // value = |gradient| exp(-(rx^2 + ry^2) / 8) 2^-63 (gj carries the table's 2^-63, the row's entry is taken without it): a NORMAL float
+            // with all 24 bits, like the shares va / vb below; the other 2^-63 rides on the y weights, so only the eight final products land in
+            // the denormal / first normal binade (at most sqrt(2) 2^-126: bits linear in the value, units of 2^-24 of the reference's scale) --
+            // one rounding per contribution.  (The first round-6 form carried 2^-126 on `v` itself: v, its two shares and the product were each
+            // rounded to the unit, 1.65e-5 instead of 6.8e-7 L2 on a low-contrast descriptor of the sweep: profiles/sweep_cases_r06.log.)
+            const float v = (mag * gj) * (gi * 0x1p63f);
             {   // addFeature :82-117.  The reference calls addValue for the 8 trilinear corners, each with its own range test
                 // and bin wrap (:59-79); here one test per cell corner, and the upper orientation bin is the next slot.
                 // The "upper" corner is floor + 1 here, not ceil: they differ only when the coordinate is an integer, and then
@@ -1331,7 +1359,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 // x - floor(x) is exact (no rounding) for the finite values here.
                 const float fx = __builtin_floorf(bx), fy = __builtin_floorf(by), fb = __builtin_floorf(bin);
                 const float iMax = bx - fx, iMin = 1.0f - iMax;
-                const float jMax = by - fy, jMin = 1.0f - jMax;
+                const float jMax = (by - fy) * 0x1p-63f, jMin = 0x1p-63f - jMax;   // the y weights, x 2^-63 (exact: powers of two)
                 // cell c in {0, 1, 2, 3} <=> bits(c) <= bits(3.0f): negative floors have the sign bit set, larger ones larger bits (the
                 // floor of a value in [0, 1) is +0)
                 const bool xa = __float_as_uint(fx) <= 0x40400000u, xb = __float_as_uint(fx + 1.0f) <= 0x40400000u;
