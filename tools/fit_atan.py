@@ -4,7 +4,10 @@ atan2 over random arguments.
 usage: python tools/fit_atan.py [n_terms] [pin]
   pin: the fit is constrained to be exact at t = tan(pi / 8) = sqrt(2) - 1 -- the argument of an exactly diagonal gradient
        (|dx| == |dy|), which sits on a boundary of the 36-bin orientation histogram (4.5 and 13.5 bins); also emulates the bin
-       decision against the reference's f32 expression round(36 (atan2f / 2 pi)) on gradients on and next to the diagonal."""
+       decision against the reference's f32 expression round(36 (atan2f / 2 pi)) on gradients on and next to the diagonal.
+       NB the emulation's sqrt and division are correctly rounded; v_sqrt_f32 / v_rcp_f32 are not, and on the GPU exact diagonals scatter
+       over both sides of the boundary whatever the bias -- which is why orientation_kernel sends the samples next to a boundary through
+       the octant form instead (NOTEBOOK.md section 14); the pinned coefficients are the shipped ones."""
 import sys
 import numpy as np
 
