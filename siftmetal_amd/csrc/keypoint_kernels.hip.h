@@ -27,7 +27,10 @@ namespace siftmi {
 #define SIFTMI_PI_F 3.14159265358979323846264338327950288f
 
 #ifndef SIFTMI_DESC_NCOPY
-#define SIFTMI_DESC_NCOPY 4                                // private histogram copies per wavefront in descriptor_kernel (tuning experiments override it)
+#define SIFTMI_DESC_NCOPY 2                                // private histogram copies per wavefront in descriptor_kernel (tuning experiments override it)
+#endif
+#ifndef SIFTMI_DESC_PACK2
+#define SIFTMI_DESC_PACK2 1                                // 1: a histogram slot is a pair of u32 and a corner is ONE 64-bit LDS add (descriptor_kernel)
 #endif
 #ifndef SIFTMI_ORI_NCOPY
 #define SIFTMI_ORI_NCOPY 4                                 // same for the 36-bin histogram of orientation_kernel
@@ -1170,9 +1173,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     // fall into the same cell and bin, and same-address lanes of one LDS add serialise.  The copies of a slot are INTERLEAVED (u32 index
     // = slot * NCOPY + copy, round 3): four neighbouring lanes that hit the same bin then touch four neighbouring banks.
     constexpr int NCOPY = SIFTMI_DESC_NCOPY;
-#ifdef SIFTMI_DESC_PACK2
-    // experiment: a slot is a PAIR of u32 -- {contributions to bin fb, contributions to bin fb + 1 from samples whose lower bin is fb} -- so that
-    // a corner is ONE 64-bit LDS add (lo = w va, hi = w vb: neither half can carry, see the bound above); bin b = lo[b] + hi[b - 1]
+#if SIFTMI_DESC_PACK2
+    // A slot is a PAIR of u32 -- {contributions to bin fb, contributions to bin fb + 1 from samples whose lower bin is fb} -- so that a corner
+    // is ONE 64-bit LDS add (lo = w va, hi = w vb; neither half can carry: the bound above), four per sample instead of eight; bin b =
+    // lo[b] + hi[b - 1].  Identical records (integer sums).  With TWO copies the 16 u64 banks of an LDS add hold (bin, copy) one to one --
+    // lanes of one cell with different orientation bins are what a wavefront mostly adds at once --: 3.95 against 4.07 ms per 1.13 M
+    // descriptors for the u32 form with four copies; four copies of pairs alias bin b with b + 4: 4.5 ms (profiles/desc_variants_r06.log).
     constexpr bool PACK2 = true;
     constexpr int NSLOT = 8, SLOTW = 2;
 #else
@@ -1208,7 +1214,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     // 0, 2, 4, 6 against 1, 3, 5, 7), and the copy is (p & 1) -- horizontal neighbours -- with the block's index above it.
     const int qpos = (lane & ~0x28) | ((lane & 8) << 2) | ((lane & 32) >> 2);
     static_assert(NCOPY == 2 || NCOPY == 4 || NCOPY == 8, "copy = one column bit + block bits");
+#ifdef SIFTMI_DESC_COPY_BLOCK_FIRST
+    const int copy = ((qpos >> 4) & 1) | ((qpos & (NCOPY / 2 - 1)) << 1);     // experiment: block bit first
+#else
     const int copy = (qpos & 1) | (((qpos >> 4) & (NCOPY / 2 - 1)) << 1);
+#endif
     const float hist_base_f = (float)((unsigned)(size_t)(lds_u32_t *)hist0 + 4u * SLOTW * (unsigned)copy);
     unsigned char *tab = lds_raw + wv * TAB_BYTES;
     float *gtab = reinterpret_cast<float *>(tab);                                        // exp(-k^2 / 8 hw^2) 2^-63 (2^-half_shift folded in), k = -radius ... radius + 3
