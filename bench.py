@@ -151,8 +151,23 @@ def cpu_baseline(frames, seconds_budget=16.0):
     odir = os.path.join(ROOT, "oracle")
     tuned = os.path.join(odir, "libsift_oracle_tuned.so")
     lib = tuned if os.path.exists(tuned) else os.path.join(odir, "libsift_oracle.so")
-    threads_hw = os.cpu_count() or 1
+    threads_hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     workers = max(1, threads_hw // 2) if threads_hw >= 16 else threads_hw      # physical cores of an SMT host
+    # ... of which a container may only get a share: the pool's boxes show 256 hardware threads under a cgroup quota of 16 CPUs (cpu.max
+    # "1600000 100000"; tools/cpu_quota_probe.py: 128 busy loops run 12.5x one).  More workers than the quota only throttle each other
+    # (rounds 3-5: "9-11 effective cores of 128").
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    if quota:
+        workers = max(1, min(workers, int(quota)))
     workers = min(workers, int(os.environ.get("SIFTMI_BENCH_CPU_WORKERS", "100000")))
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
     fd, path = tempfile.mkstemp(suffix=".npy", prefix="siftmi_cpu_baseline_", dir=shm)
@@ -180,6 +195,7 @@ def cpu_baseline(frames, seconds_budget=16.0):
         done, n_desc = sum(r["frames"] for r in res), sum(r["descriptors"] for r in res)
         span = max(r["seconds"] for r in res)                 # the workers start within a fraction of a second of each other
         out = {"value": round(done * W * H / span / 1e6, 3), "unit": "Mpixels/s", "cores": len(res), "kind": "port",
+               "host": {"hardware_threads": threads_hw, "cgroup_cpu_quota": quota},
                "implementation": "oracle/sift_oracle.c (CPU restatement of the reference's algorithm, stage by stage) built -O3 -march=x86-64-v3 "
                                  "(%s); %d single-threaded worker processes, one frame at a time each" % (os.path.basename(lib), len(res)),
                "sample": "%d x %dx%d synthetic frames (same generator), %d octaves, %.1f s (%.1f s with process start-up), %d descriptors" %

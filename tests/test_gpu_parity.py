@@ -614,6 +614,9 @@ def test_dense_natural_texture_1080p_vs_oracle(sm, butterfly_bgra):
         r_desc, r_f32 = orc.descriptors(o, okp, in_ori, want_float=True)
         drep = parity.compare_descriptors(got_d[o], eng.descriptor_floats(o), r_desc, r_f32, in_ori)
         assert drep["max_bin_diff"] <= 1 and drep["bins_differing"] <= parity.bins_allowed(drep["bins"]) and drep["max_l2_float"] <= parity.TOL_DESC_L2, drep
+        # round 6 spends precision on this content on purpose (2^-24 fixed-point contributions, six-term atan, table weights: DESIGN.md
+        # section 3) and promised to stay an order of magnitude inside the tolerance on natural frames: 3.1e-6 observed, 1e-5 asserted
+        assert drep["max_l2_float"] <= 1e-5 and drep["bins_differing"] <= max(3, 2e-4 * drep["bins"]), drep
     assert match >= 0.995 * tot, (match, tot)
 
 
