@@ -846,6 +846,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
     const int n = min(kp_count[group], P.cap_kp[o]);
     const int w = P.w[o], h = P.h[o];
     const float delta = P.delta[o], lambda = prm.lambda_ori;
+    // delta = delta_min 2^o with delta_min = 0.5 (siftmi_create accepts nothing else): a power of two, so x / delta == x * (1 / delta) bit for
+    // bit -- five IEEE divisions (~10 vector instructions each, executed by all 64 lanes on wave-uniform values) less per keypoint
+    const float inv_delta = 1.0f / delta;
     const size_t base = (size_t)frame * P.kp_frame + P.kp_off[o];
     const int k_first = COOP ? (int)blockIdx.x : (int)(blockIdx.x * WPB + wv), k_step = COOP ? (int)gridDim.x : (int)(gridDim.x * WPB);
     KeypointRec kp_next = kps[base + min(k_first, max(n - 1, 0))];      // the record of a wave's NEXT keypoint is requested a keypoint ahead
@@ -855,8 +858,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         bool reject;
         {   // SIFTOctave.swift:303-329
             const float minX = 1.0f, minY = 1.0f, maxX = (float)(w - 2), maxY = (float)(h - 2);
-            const float x = kp.abs_x / delta, y = kp.abs_y / delta;
-            const float sigma = kp.sigma / delta;
+            const float x = kp.abs_x * inv_delta, y = kp.abs_y * inv_delta;   // (/ delta: exact either way, delta is a power of two)
+            const float sigma = kp.sigma * inv_delta;
             const float r = ceilf(3.0f * lambda * sigma);
             reject = (floorf(x - r) < minX) || (ceilf(x + r) > maxX) || (floorf(y - r) < minY) || (ceilf(y + r) > maxY);
         }
@@ -870,9 +873,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(SIFTMI
         for (int c = lidx; c < OCOPY * OSTRIDE; c += STRIDE) hist0[c] = 0u;
         int half_shift = 0;
         {   // SIFTOrientation.metal:87-136
-            const int x = (int)roundf((float)absoluteX / delta);
-            const int y = (int)roundf((float)absoluteY / delta);
-            const float sigma = kp.sigma / delta;
+            const int x = (int)roundf((float)absoluteX * inv_delta);
+            const int y = (int)roundf((float)absoluteY * inv_delta);
+            const float sigma = kp.sigma * inv_delta;
             const float exponentDenominator = 2.0f * lambda * lambda;
             // per keypoint: the reciprocals the sample loop multiplies by (the reference divides per sample; float note at
             // descriptor_kernel: the weight of a sample moves by 1-2 ulp, the bin it goes to does not depend on it), with
