@@ -13,7 +13,9 @@ import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 F = 64
 patch = 1 if (len(sys.argv) > 3 and sys.argv[3] == "patch") else 0      # siftmi_config.descriptor_patch_lds
-eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=F, descriptor_patch_lds=patch)
+import json
+extra = json.loads(os.environ.get("SIFTMI_ENGINE_KW", "{}"))                # e.g. SIFTMI_ENGINE_KW='{"blur_chain_max_tiles": 4096}'
+eng = sm.Engine(1920, 1080, n_octaves=4, max_batch=F, descriptor_patch_lds=patch, **extra)
 fs = smstream.FrameStream(eng, F)
 kind = sys.argv[2] if len(sys.argv) > 2 else "dense"
 d = smstream.DeviceFrames(bench.make_dense_frames(F) if kind == "dense" else bench.make_frames(F, 16))
@@ -30,5 +32,5 @@ r = fs.results_host()
 import hashlib
 import numpy as np
 digest = hashlib.sha256(np.ascontiguousarray(r["keypoints"]).tobytes() + np.ascontiguousarray(r["descriptors"]).tobytes()).hexdigest()[:16]
-print(os.environ.get("SIFTMI_LIB", "libsiftmi.so") + (" descriptor_patch_lds=1" if patch else ""), {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0}, r["n_keypoints"], r["n_descriptors"],
+print(os.environ.get("SIFTMI_LIB", "libsiftmi.so") + (" descriptor_patch_lds=1" if patch else "") + (" " + json.dumps(extra) if extra else ""), {k: round(v[0] / steps, 3) for k, v in tm.items() if v[0] > 0}, r["n_keypoints"], r["n_descriptors"],
       "sha256 of the packed records", digest, flush=True)
