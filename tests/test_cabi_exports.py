@@ -179,3 +179,23 @@ def test_asm_prefetch_registers_are_not_touched_in_flight():
     out = p.stdout.decode()
     assert p.returncode == 0, out
     assert int(re.search(r"audited (\d+) asm loads", out).group(1)) >= 100, out
+
+
+def test_makefile_lists_every_part_of_the_translation_unit():
+    """csrc/siftmi_api.hip is one translation unit in parts (`#include "x.hip.h"`): every part, and every header a part includes, is a
+    prerequisite of libsiftmi.so in csrc/Makefile (a stale library after an edit to a part would pass every CPU-side check)."""
+    csrc = os.path.join(ROOT, "siftmetal_amd", "csrc")
+    hdr_line = [l for l in open(os.path.join(csrc, "Makefile")).read().splitlines() if l.startswith("HDR")][0]
+    listed = {os.path.basename(t) for t in hdr_line.split("=", 1)[1].split()}
+    seen, todo = set(), ["siftmi_api.hip"]
+    while todo:
+        f = todo.pop()
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(os.path.join(csrc, f)).read(), re.M):
+            base = os.path.basename(inc)
+            if base not in seen:
+                seen.add(base)
+                assert os.path.exists(os.path.join(csrc, inc)), inc
+                if os.path.dirname(inc) == "":
+                    todo.append(inc)
+    assert seen <= listed, "not prerequisites of ../libsiftmi.so in csrc/Makefile: %s" % sorted(seen - listed)
+    assert {"launch_sequence.hip.h", "batch_api.hip.h", "describe_match_api.hip.h", "inspect_api.hip.h"} <= seen
