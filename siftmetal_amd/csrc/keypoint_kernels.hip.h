@@ -1122,6 +1122,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// maximum over the 64 lanes of a value >= +0, the same on every lane (the DPP tree of wave_sum; lanes without a source contribute 0)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+#define WMAX_DPP(CTRL, ROWMASK) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false)))
+    WMAX_DPP(0x111, 0xf); WMAX_DPP(0x112, 0xf); WMAX_DPP(0x114, 0xf); WMAX_DPP(0x118, 0xf);
+    WMAX_DPP(0x142, 0xa); WMAX_DPP(0x143, 0xc);
+#undef WMAX_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // COOP = false: one wavefront per descriptor (large launches: there are more descriptors than wavefronts in flight).
 // COOP = true: the four wavefronts of a workgroup share one descriptor -- for a frame or two there are fewer descriptors than
 // wavefront slots, and a descriptor's ~3000 samples walked by 64 lanes take 60-100 us of dependent loads and LDS atomics;
@@ -1131,6 +1140,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // idles at workgroup tails on dense frames (4.35 of 6 resident, PMC round 4)
 #ifndef SIFTMI_DESC_QCAP
 #define SIFTMI_DESC_QCAP 832                              // entries of the walk's quad table (0: the row-advance walk of round 5)
+#endif
+#ifndef SIFTMI_DESC_FLAG_SS
+#define SIFTMI_DESC_FLAG_SS 0.25f                           // squared norm (reference units) below which a descriptor goes to the second pass: (2^23 units)^2
 #endif
 #ifndef SIFTMI_DESC_WAVES
 #define SIFTMI_DESC_WAVES 7                                // wavefronts per SIMD the descriptor kernel's register budget is sized for (72 VGPRs);
@@ -1167,11 +1179,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 // window's texels are used ~4 times each and the L1 / L2 already serve that (profiles/pmc_descriptor_dense_r05.txt: 0.9 MB fetched from HBM
 // by 2 M workgroups), while tiles of the bounding box visit the corners the compacted row walk skips and every 256 samples wait for a
 // load -> LDS -> read round trip (profiles/desc_patch_lds_r05.log; the PATCH form needs 5 wavefronts' worth of registers per SIMD and says so).
-template <bool COOP, int WPB = 4, bool PATCH = false>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH ? 5 : SIFTMI_DESC_WAVES + (WPB == 1 ? 1 : 0)))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
+// REFINE (round 6, late) -- low-contrast windows.  The 2^-24 unit is ABSOLUTE: a window whose gradients are ~1e-3 keeps ~10 bits per
+// contribution, and its unit vector then differs from the oracle's by up to 2e-5 with one integer in 200 off by one (two cases of 240 in
+// the sweeps; rounds 2-5, 2^-32: 4e-7 / none).  The roundings add up to ~45 units over a descriptor whatever its contrast, so the NORM of
+// the accumulated bins says which descriptors are affected: the launch flags those whose norm is below 2^23 units (expected error above
+// ~5e-6; `desc_flag`, one int per descriptor), and a second, small launch -- this kernel with REFINE = true -- walks the flagged ones again
+// with the unit 2^-24 4^-fine_h, fine_h = 4, 3, ... (the windows the sweeps found worst are LARGE ones, hw > 17 with seven scales per octave, whose
+// default unit is 2^-22: unit_shift).  A finer unit is only valid while every contribution stays in the linear range of the bit trick,
+// 2 |gradient| 4^fine_h < 2, and every bin's sum below 2^32 units, so the REFINE walk keeps the largest squared gradient of the contributing
+// samples and accepts the first unit that passes both; if none finer than the default does, the first launch's record stands.
+// Flag and acceptance depend on integer sums and on the set of contributing samples only: every launch form gives the same bytes.  The
+// default launch's loop is untouched (the flag is one compare in its epilogue).
+// Every sweep case past 6e-6 had six or seven scales per octave -- the reference sizes descriptor windows with a literal 3 scales per octave
+// (SIFTOctave.swift:398), so there hw reaches 24 and the default unit is 2^-22 -- and none with up to five (hw <= 17.1): the host launches
+// the second pass (and passes `desc_flag`) only for schedules whose windows can reach hw >= 17 (siftmi_create: desc_refine); with the
+// reference's own schedule nothing is flagged and nothing is launched.
+template <bool COOP, int WPB = 4, bool PATCH = false, bool REFINE = false>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH ? 5 : (REFINE ? 4 : SIFTMI_DESC_WAVES + (WPB == 1 ? 1 : 0))))) void descriptor_kernel(PyramidDesc P, DetectParams prm,
                                                         const KeypointRec *__restrict__ kps, const DescInput *__restrict__ desc_in,
                                                         const int32_t *__restrict__ desc_count, DescriptorRec *__restrict__ desc_out,
-                                                        float *__restrict__ desc_f32 /* may be null */) {
+                                                        float *__restrict__ desc_f32 /* may be null */, int32_t *__restrict__ desc_flag) {
+    static_assert(!REFINE || (!COOP && !PATCH), "the second pass is the plain one-wavefront-per-descriptor form");
     // NCOPY private copies of the histogram per wave (copy = lane % NCOPY): neighbouring lanes take neighbouring samples, which mostly
     // fall into the same cell and bin, and same-address lanes of one LDS add serialise.  The copies of a slot are INTERLEAVED (u32 index
     // = slot * NCOPY + copy, round 3): four neighbouring lanes that hit the same bin then touch four neighbouring banks.
@@ -1234,6 +1262,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     const int w = P.w[o], h = P.h[o];
     const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
     for (int di = COOP ? (int)blockIdx.x : (int)(blockIdx.x * WPB + wv); di < n; di += COOP ? (int)gridDim.x : (int)(gridDim.x * WPB)) {
+        if (REFINE && desc_flag[dbase + di] == 0) continue;               // (wave-uniform)
         const DescInput in = desc_in[dbase + di];                          // wave-uniform: scalar loads
         const float theta = in.theta;
         const LayerView g = layer_view(layer_ptr(P, frame, o, in.scale), w, h);
@@ -1256,17 +1285,23 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
         const float bound = (histogramWidth + 1.0f) * (histogramWidth + 1.0f) * 0.70710678f;
         int half_shift = 0;
         while (ldexpf(bound, -2 * half_shift) >= 240.0f) half_shift++;       // (wave-uniform; no trip with the reference's schedule)
-        const float gscale = ldexpf(1.0f, -63 - half_shift);
+        // REFINE: the contributions' unit is 2^-24 4^-fine_h instead of 2^-24 4^half_shift (fine_h = 4, 3, ... down to 1 - half_shift)
+        int fine_h = REFINE ? 4 : -half_shift;
+        float gscale = ldexpf(1.0f, -63 + fine_h);
         auto gauss = [&](int k) -> float { const float f = (float)k; return __builtin_amdgcn_exp2f(kg * (f * f)) * gscale; };
         const float theta_turns = theta * 0.159154943091895336f;              // theta in [0, 2 pi)
 
-        if (COOP) {
-            __syncthreads();                                                          // wave 0 is done reading the previous descriptor's bins
-            for (int c = threadIdx.x; c < HIST / 4; c += 256) reinterpret_cast<uint4 *>(hist0)[c] = make_uint4(0u, 0u, 0u, 0u);
-        } else {
-            for (int c = lane; c < HIST / 4; c += 64) reinterpret_cast<uint4 *>(hist0)[c] = make_uint4(0u, 0u, 0u, 0u);   // all copies (contiguous)
-        }
-        if (compact) for (int k = lane; k < side + 3; k += 64) gtab[k] = gauss(k - radius);
+        auto clear_bins = [&]() {
+            if (COOP) {
+                __syncthreads();                                                      // wave 0 is done reading the previous descriptor's bins
+                for (int c = threadIdx.x; c < HIST / 4; c += 256) reinterpret_cast<uint4 *>(hist0)[c] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                for (int c = lane; c < HIST / 4; c += 64) reinterpret_cast<uint4 *>(hist0)[c] = make_uint4(0u, 0u, 0u, 0u);   // all copies (contiguous)
+            }
+        };
+        auto build_gtab = [&]() { if (compact) for (int k = lane; k < side + 3; k += 64) gtab[k] = gauss(k - radius); };
+        clear_bins();
+        build_gtab();
 
         // The reference visits every (j, i) of the (2 radius + 1)^2 window (metal :194-195), but a sample adds
         // something only if its cell coordinates fall inside (-1, 4)^2, i.e. inside a rotated square of half
@@ -1330,6 +1365,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
         // candidate that is not a window sample).  INTERIOR (wave-uniform, almost every descriptor): the sample and its four neighbours
         // are inside the image, so the texels come from the walk (wide loads) and there is no per-sample range test or mirror.
 #define DESC_HADD(a, off, v) lds_add_bits((a), (off), (v))
+        float m2max = 0.0f;                                                 // REFINE: the largest (2 |gradient|)^2 among the contributing samples
         auto sample = [&](auto interior_tag, float fj, int i, float gj, float gi, float t_xp, float t_xm, float t_yp, float t_ym) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
             const float fi = (float)i;
@@ -1357,7 +1393,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
             // gradient (tx, ty) = (dx, dy) / 2 (SIFTGradient.metal:31-32): its angle atan2(tx, ty) does not depend on the factor 1/2;
             // orientation = angle - theta wrapped into [0, 2 pi), bin = 8 orientation / 2 pi (SIFTDescriptor.metal:203-213): in turns,
             // the wrap is v_fract (which stays below 1: bin < 8)
-            const float mag = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, 1.0e-30f)));       // 2 |gradient|, > 0 (angle_turns)
+            const float m2 = fmaf(dx, dx, fmaf(dy, dy, 1.0e-30f));
+            const float mag = __builtin_amdgcn_sqrtf(m2);                                         // 2 |gradient|, > 0 (angle_turns)
             const float bin = __builtin_amdgcn_fractf(angle_turns(dx, dy, mag) - theta_turns) * 8.0f;
             // value = |gradient| exp(-(rx^2 + ry^2) / 8) 2^-63 (gj carries the table's 2^-63, the row's entry is taken without it): a NORMAL float
             // with all 24 bits, like the shares va / vb below; the other 2^-63 rides on the y weights, so only the eight final products land in
@@ -1377,6 +1414,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 // floor of a value in [0, 1) is +0)
                 const bool xa = __float_as_uint(fx) <= 0x40400000u, xb = __float_as_uint(fx + 1.0f) <= 0x40400000u;
                 const bool ya = __float_as_uint(fy) <= 0x40400000u, yb = __float_as_uint(fy + 1.0f) <= 0x40400000u;
+                if constexpr (REFINE) { if ((xa || xb) && (ya || yb)) m2max = fmaxf(m2max, m2); }
                 // the value's share of either orientation bin.  Every factor below is >= +0, so is every product: a contribution's sign
                 // bit is never set (vb <= v as a rounded product of v and a factor < 1, so v - vb >= +0 too)
                 const float vb = (bin - fb) * v, va = v - vb;
@@ -1533,10 +1571,27 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
                 }
             }
         };
-        if (interior) walk(std::true_type{}); else walk(std::false_type{});
+        bool refined = false;
+        for (;;) {
+            if (interior) walk(std::true_type{}); else walk(std::false_type{});
+            if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (!REFINE) break;
+            // was every contribution inside the linear range at this unit, 2 |gradient| 4^fine_h < 2, and is every bin's sum below 2^32 units,
+            // (hw + 1)^2 max |gradient| 4^fine_h 2^24 < 2^32 (the bound of the header, per unit of gradient)?  (with a margin for the roundings)
+            const float q = 512.0f / ((histogramWidth + 1.0f) * (histogramWidth + 1.0f));
+            refined = wave_max_nonneg(m2max) * ldexpf(1.0f, 4 * fine_h) < 0.8f * fminf(4.0f, q * q);
+            if (refined || --fine_h == -half_shift) break;
+            m2max = 0.0f;                                                        // no: the same walk at the next coarser unit
+            gscale = ldexpf(1.0f, -63 + fine_h);
+            clear_bins();
+            build_gtab();
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
 #undef DESC_HADD
-        if (COOP) { __syncthreads(); if (wv != 0) continue; } else __builtin_amdgcn_wave_barrier();   // COOP: wave 0 finishes the descriptor
-        __threadfence_block();
+        if (REFINE && !refined) continue;                                        // the first launch's record stands
+        if (COOP && wv != 0) continue;                                           // COOP: wave 0 finishes the descriptor
         // features lane and lane + 64 (feature = cell * 8 + bin): the NCOPY copies of their slot, and for bin 0 those of slot 8.
         // Sums stay below 2^32 (header).
         unsigned a0 = 0u, a1 = 0u;
@@ -1557,10 +1612,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
             }
             }
         }
-        const float unit_scale = ldexpf(1.0f, -24 + 2 * half_shift);        // back to the reference's units (the normalisation removes it again)
+        const float unit_scale = ldexpf(1.0f, -24 - 2 * fine_h);           // back to the reference's units (the normalisation removes it again)
         float f0 = (float)a0 * unit_scale, f1 = (float)a1 * unit_scale;
         {   // normalise -> clamp 0.2 -> normalise (:15-39, :224-227)
-            float dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));
+            const float ss = wave_sum(f0 * f0 + f1 * f1);
+            // norm below 2^23 units of 2^-24 (the roundings' ~45 units are then more than ~5e-6 of it): for the second launch (header)
+            if (!REFINE && desc_flag != nullptr && lane == 0) desc_flag[dbase + di] = (ss > 0.0f && ss < SIFTMI_DESC_FLAG_SS * unit_scale * unit_scale * 0x1p48f) ? 1 : 0;
+            float dn = 1.0f / sqrtf(ss);
             f0 *= dn; f1 *= dn;
             f0 = fminf(f0, 0.2f); f1 = fminf(f1, 0.2f);
             dn = 1.0f / sqrtf(wave_sum(f0 * f0 + f1 * f1));

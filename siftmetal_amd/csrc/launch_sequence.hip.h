@@ -421,19 +421,27 @@ static int run_describe(siftmi_ctx *c, hipStream_t st, int nf, int only_octave =
     // a frame or two: fewer descriptors than wavefront slots -> one workgroup per descriptor (see descriptor_kernel)
     if (coop)
         hipLaunchKernelGGL((descriptor_kernel<true, 4>), dim3((unsigned)exp_knob("SIFTMI_EXP_COOP_WG", 1024), groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
-                           c->d_desc_f32);
+                           c->d_desc_f32, c->d_desc_flag);
     else {
         if (wpb_desc == 1 && c->cfg.descriptor_patch_lds)
             hipLaunchKernelGGL((descriptor_kernel<false, 1, true>), dim3(wg1, groups), dim3(64), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC),
-                               c->d_desc, c->d_desc_f32);
+                               c->d_desc, c->d_desc_f32, c->d_desc_flag);
         else if (wpb_desc == 1)
             hipLaunchKernelGGL((descriptor_kernel<false, 1>), dim3(wg1, groups), dim3(64), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
-                               c->d_desc_f32);
+                               c->d_desc_f32, c->d_desc_flag);
         else
             hipLaunchKernelGGL((descriptor_kernel<false, 4>), dim3(256, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC), c->d_desc,
-                               c->d_desc_f32);
+                               c->d_desc_f32, c->d_desc_flag);
     }
     HIP_TRY(hipGetLastError());
+    // second pass, only for schedules with very wide descriptor windows (siftmi_create: desc_refine; never the reference's default): the
+    // descriptors the first pass flagged as low-contrast, at a finer fixed-point unit -- the same form after every first-pass form, so that
+    // all of them give the same bytes (descriptor_kernel, REFINE)
+    if (c->desc_refine) {
+        hipLaunchKernelGGL((descriptor_kernel<false, 4, false, true>), dim3(coop ? 16 : 64, groups), dim3(256), 0, st, P, c->prm, c->d_kp, c->d_desc_in, cnt(c, C_DESC),
+                           c->d_desc, c->d_desc_f32, c->d_desc_flag);
+        HIP_TRY(hipGetLastError());
+    }
     t_end(c);
     return SIFTMI_OK;
 }

@@ -137,6 +137,9 @@ struct siftmi_ctx {
     int32_t *d_ori_count = nullptr;
     float *d_ori_angles = nullptr;
     DescInput *d_desc_in = nullptr;
+    int32_t *d_desc_flag = nullptr;            // per descriptor: 1 = low-contrast window, the second descriptor launch walks it again (descriptor_kernel, REFINE);
+                                              // null unless the schedule has windows wide enough to need it (desc_refine)
+    bool desc_refine = false;
     DescriptorRec *d_desc = nullptr;
     float *d_desc_f32 = nullptr;
     int32_t *d_counters = nullptr;            // [5][B*n_oct]: raw, cand, kp, oriented, desc
@@ -293,7 +296,7 @@ static void free_ctx(siftmi_ctx *c) {
     (void)hipDeviceSynchronize();             // nothing of this context may still be running when its memory and graphs go
     void *ptrs[] = {c->d_gauss, c->d_input, c->d_ext, c->d_kp_tmp, c->d_kp, c->d_keys, c->d_bucket_keys, c->d_bucket_src, c->d_row_count,
                     c->d_row_start, c->d_act, c->d_ori_count, c->d_ori_angles,
-                    c->d_desc_in, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_out_kp,
+                    c->d_desc_in, c->d_desc_flag, c->d_desc, c->d_desc_f32, c->d_counters, c->d_dst_off, c->d_out_kp,
                     c->d_out_desc, c->d_out_counts, c->d_stats, c->d_match_src, c->d_match_tgt, c->d_match_out, c->d_match_scratch, c->d_match_sync};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -450,6 +453,12 @@ extern "C" int siftmi_create(const siftmi_config *cfg, int hip_device, siftmi_ct
     alloc((void **)&c->d_ori_count, B * kp_off * sizeof(int32_t));
     alloc((void **)&c->d_ori_angles, B * kp_off * ORI_BINS * sizeof(float));
     alloc((void **)&c->d_desc_in, B * desc_off * sizeof(DescInput));
+    {   // the widest descriptor window of this schedule: hw = 3 sigma 2^(interval / descriptor_scales_per_octave), interval < nspo + 1 (make_desc_input);
+        // from hw ~ 17.4 on a window's fixed-point unit is 2^-22 and low-contrast windows get the second descriptor pass (descriptor_kernel, REFINE)
+        const float hw_max = 3.0f * 1.6f * powf(2.0f, ((float)c->nspo + 1.0f) / (float)std::max(1, cfg->descriptor_scales_per_octave));
+        c->desc_refine = hw_max >= 17.0f;
+    }
+    if (c->desc_refine) alloc((void **)&c->d_desc_flag, B * desc_off * sizeof(int32_t));
     alloc((void **)&c->d_desc, B * desc_off * sizeof(DescriptorRec));
     if (cfg->keep_descriptor_floats) alloc((void **)&c->d_desc_f32, B * desc_off * DESC_N * sizeof(float));
     alloc((void **)&c->d_counters, 5 * G * sizeof(int32_t) + sizeof(PackState));

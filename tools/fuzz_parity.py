@@ -33,7 +33,8 @@ def main():
                 worst_theta = max(worst_theta, r["max_dtheta"])
             print("ok   %s%s -> %d keypoints, %d of %d angles over 2e-3 rad (max %.2e)%s, descriptor L2 %.2e, %d bins differ" %
                   (tag, " (raised capacities)" if r["raised_capacities"] else "", r["keypoints"], r["angles_over_tol"], r["angles_compared"], r["max_dtheta"],
-                   " [symmetric pattern]" if r["symmetric_pattern"] else "", r["max_l2_float"], r["bins_differing"]), flush=True)
+                   (" [symmetric pattern; %d orientation counts differ]" % r["orientation_count_mismatch"]) if r["symmetric_pattern"] else "", r["max_l2_float"],
+                   r["bins_differing"]), flush=True)
         except AssertionError:
             fails += 1
             print("FAIL %s" % tag, flush=True)
