@@ -45,7 +45,9 @@ typedef enum siftmi_status {
 /* Pixel formats.  The reference accepts only a .bgra8Unorm texture
    (Metal Compute/ConvertSRGBToGrayscaleKernel.swift:34); GRAY8/GRAYF32 skip the luma step.
    SIFTMI_FMT_GRAYF32 pixels are the luma itself and must lie in [0, 1], the range a unorm texture delivers: thresholds are absolute
-   and the orientation / descriptor histograms are accumulated in 2^-24 fixed point (u32 bins sized for gradients of a [0, 1] image),
+   and the orientation / descriptor histograms are accumulated in 2^-24 fixed point (u32 bins sized for gradients of a [0, 1] image; 2^-22
+   for descriptor windows wider than histogramWidth 17.4 -- six or seven scales per octave -- whose low-contrast ones are walked a second time
+   at a finer unit),
    which overflows for an unnormalised (0 ... 255, HDR) image.  A frame with a value outside [0, 1] (or a NaN) is reported: SIFTMI_E_BADARG from the
    host-facing entry points, overflow_flags bit 5 on the device path; its results are not to be used. */
 typedef enum siftmi_format {
