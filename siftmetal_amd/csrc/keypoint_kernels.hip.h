@@ -1261,8 +1261,25 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(PATCH 
     const int n = min(desc_count[group], P.cap_desc[o]);
     const int w = P.w[o], h = P.h[o];
     const size_t dbase = (size_t)frame * P.desc_frame + P.desc_off[o];
-    for (int di = COOP ? (int)blockIdx.x : (int)(blockIdx.x * WPB + wv); di < n; di += COOP ? (int)gridDim.x : (int)(gridDim.x * WPB)) {
-        if (REFINE && desc_flag[dbase + di] == 0) continue;               // (wave-uniform)
+    // REFINE: a wavefront reads the flags of 64 descriptors at a time (one coalesced load and a ballot, not one scalar load per descriptor:
+    // the flagged ones are a handful per group) and walks the flagged ones
+    const int di_step = COOP ? (int)gridDim.x : (int)(gridDim.x * WPB);
+    int di = (COOP ? (int)blockIdx.x : (int)(blockIdx.x * WPB + wv)) - di_step;
+    int chunk = (int)(blockIdx.x * WPB + wv) * 64 - di_step * 64;
+    unsigned long long pending = 0ull;
+    for (;;) {
+        if constexpr (REFINE) {
+            while (pending == 0ull) {
+                chunk += di_step * 64;
+                if (chunk >= n) return;                                      // (wave-uniform; no workgroup barriers in this form)
+                pending = __ballot(chunk + lane < n && desc_flag[dbase + chunk + lane] != 0);
+            }
+            di = chunk + __builtin_ctzll(pending);
+            pending &= pending - 1ull;
+        } else {
+            di += di_step;
+            if (di >= n) break;
+        }
         const DescInput in = desc_in[dbase + di];                          // wave-uniform: scalar loads
         const float theta = in.theta;
         const LayerView g = layer_view(layer_ptr(P, frame, o, in.scale), w, h);
